@@ -1,0 +1,81 @@
+"""Oracle train-step glue: DDPM schedule closed forms, losses, one optimizer step.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+The reference takes these from `monai-generative` (`generative.networks.schedulers.
+DDPMScheduler`, T-LDM:74,160,165; T-DDPM:380), which is absent from /root/reference and
+from this image (unpinned dependency, pyproject.toml:20-33).  The formulas below are the
+published DDPM / LDM closed forms; nothing under /root/reference pins them, so the
+schedule itself is "parity unpinned" (DESIGN.md).  The step order follows T-LDM:145-180 /
+T-DDPM:183-200; optimizer and clipping are torch's own (`torch.optim.Adam[W]`,
+`clip_grad_norm_`), exactly what the reference calls.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+class DDPMSchedule:
+    """betas / alphas_cumprod of DDPMScheduler(num_train_timesteps, schedule, beta_start, beta_end)."""
+
+    def __init__(self, num_train_timesteps: int = 1000, schedule: str = "scaled_linear_beta",
+                 beta_start: float = 0.0015, beta_end: float = 0.0205, prediction_type: str = "epsilon"):
+        if schedule == "scaled_linear_beta":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        elif schedule == "linear_beta":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        else:
+            raise ValueError(f"unknown schedule {schedule}")
+        self.num_train_timesteps = num_train_timesteps
+        self.prediction_type = prediction_type
+        self.betas = betas
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+
+    def _coef(self, timesteps, ndim):
+        a = self.alphas_cumprod[timesteps]
+        shape = (-1,) + (1,) * (ndim - 1)
+        return (a ** 0.5).reshape(shape), ((1 - a) ** 0.5).reshape(shape)
+
+    def add_noise(self, original_samples, noise, timesteps):
+        sa, so = self._coef(timesteps, original_samples.ndim)
+        return sa * original_samples + so * noise
+
+    def get_velocity(self, sample, noise, timesteps):
+        sa, so = self._coef(timesteps, sample.ndim)
+        return sa * noise - so * sample
+
+
+def kl_loss(z_mu, z_sigma):
+    """AutoEncoder.get_kl_loss, T-AE:68-72."""
+    kl = 0.5 * (z_mu.pow(2) + z_sigma.pow(2) - torch.log(z_sigma.pow(2)) - 1)
+    kl = torch.sum(kl, dim=list(range(1, z_mu.ndim)))
+    return torch.sum(kl) / kl.shape[0]
+
+
+def ddpm_loss(model, schedule: DDPMSchedule, x0, noise, timesteps):
+    """q-sample -> model -> MSE (T-LDM:159-169 / T-DDPM:185-192)."""
+    noisy = schedule.add_noise(x0, noise, timesteps)
+    pred = model(noisy, timesteps)
+    target = schedule.get_velocity(x0, noise, timesteps) if schedule.prediction_type == "v_prediction" else noise
+    return F.mse_loss(pred.float(), target.float()), pred
+
+
+def ddpm_train_step(model, optimizer, schedule, x0, noise, timesteps, max_norm: float | None = 1.0):
+    """backward -> clip_grad_norm_ -> step -> zero_grad (T-LDM:171-180)."""
+    loss, pred = ddpm_loss(model, schedule, x0, noise, timesteps)
+    loss.backward()
+    if max_norm:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    return loss.detach(), pred.detach()
+
+
+def ae_loss(model, images, eps, kl_weight: float):
+    """Generator-side AE loss without the third-party perceptual/adversarial terms
+    (T-AE:411-414): L1 reconstruction + kl_weight * KL."""
+    recon, z_mu, z_sigma = model(images, eps)
+    rec = F.l1_loss(recon.float(), images.float())
+    reg = kl_loss(z_mu, z_sigma) * kl_weight
+    return rec + reg, recon, z_mu, z_sigma
