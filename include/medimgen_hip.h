@@ -1,0 +1,117 @@
+/* medimgen_hip.h -- C ABI of libmedimgen_hip.so: the MI355X (gfx950) kernels behind the train step of
+ * VKostoulas/Medical_Image_Generation's DiffusionModelUNet / AutoencoderKL "with strides".
+ *
+ * The reference has no FFI: its hot path is Python calling torch/aten ops.  Each entry point below replaces the
+ * aten op family named in its comment at the cited call sites (paths relative to the reference's medimgen/ directory;
+ * UNet = diffusion_model_unet_with_strides.py, AEKL = autoencoderkl_with_strides.py, T-LDM = train_ldm.py, ...).
+ *
+ * Conventions
+ *   - plain pointers + sizes; every pointer is DEVICE memory unless named host_*; no torch types.
+ *   - activations: channels-last  [N][D][H][W][cstride]  bf16 (2-D nets: D = 1); `cstride` >= C is the element pitch of
+ *     one voxel so a tensor can live inside a wider (concat) buffer.  Model boundary: NCDHW fp32.
+ *   - weights / gradients / optimizer state: fp32, torch layouts ([Cout][Cin][kd][kh][kw], [out][in], [C]).
+ *   - every call enqueues on `stream` and returns immediately; return value 0 = ok, otherwise a hipError_t value, or
+ *     MI_ERR_BAD_ARG / MI_ERR_UNSUPPORTED from host-side validation (nothing was launched).  Nothing aborts.
+ *   - no call allocates, frees or synchronises (hipGraph-capturable) except mi_conv_plan_create / _destroy.
+ */
+#ifndef MEDIMGEN_HIP_H
+#define MEDIMGEN_HIP_H
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ERR_BAD_ARG 10001
+#define MI_ERR_UNSUPPORTED 10002
+
+int mi_abi_version(void);
+
+/* ---- model boundary / layout (replaces .to(device) + autocast casts, T-LDM:144,148) ------------------------------------ */
+int mi_ncdhw_f32_to_ndhwc_bf16(const float* src, void* dst, int N, int C, int64_t V, hipStream_t stream);
+int mi_ndhwc_bf16_to_ncdhw_f32(const void* src, float* dst, int N, int C, int64_t V, hipStream_t stream);
+int mi_cast_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t stream);
+int mi_cast_bf16_to_f32(const void* src, float* dst, int64_t n, int accumulate, hipStream_t stream);
+
+/* ---- aten::add (residuals UNet:695,701,458; AEKL:204,323), aten::cat (UNet:1263,1377,1504) ------------------------------ */
+int mi_add_bf16(const void* a, const void* b, void* out, int64_t n, hipStream_t stream);
+int mi_copy_channels(const void* src, int Cs, int c0s, void* dst, int Cd, int c0d, int nC, int64_t nvox, hipStream_t stream);
+
+/* ---- aten::upsample_nearest3d (+backward): F.interpolate(mode="nearest"), UNet:580, AEKL:99 ----------------------------- */
+int mi_upsample_nearest_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t stream);
+int mi_upsample_nearest_bwd(const void* dy, void* dx, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t stream);
+/* space<->depth rearrangement used by strided convolutions; (D,H,W,C) always describe the SPACE-side tensor */
+int mi_space_to_depth(const void* in, void* out, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t stream);
+int mi_depth_to_space(const void* in, void* out, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t stream);
+
+/* ---- aten::native_group_norm (+backward) fused with aten::silu: nn.GroupNorm + nn.SiLU, UNet:628-629,648,377,1932-1933;
+ *      AEKL:157,167,194,198,238,451,604 ----------------------------------------------------------------------------------- */
+int64_t mi_gn_workspace_bytes(int N, int64_t V, int C);
+/* statistics -> scale_shift[N][C][2] (= gamma*rstd, beta-mean*gamma*rstd) and mean_rstd[N][G][2] */
+int mi_gn_stats(const void* x, int x_cstride, int N, int64_t V, int C, int G, float eps, const float* gamma, const float* beta,
+                float* scale_shift, float* mean_rstd, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* y = (silu?)(x*scale+shift) */
+int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y, int y_cstride, int N, int64_t V, int C, int silu,
+                hipStream_t stream);
+/* g = dL/d(output of norm[+silu]);  dx = GN/SiLU backward (+ add);  dgamma/dbeta are ACCUMULATED (fp32);  coef: [N][C][3] scratch */
+int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N, int64_t V, int C, int G, const float* gamma,
+              const float* scale_shift, const float* mean_rstd, int silu, const void* add, int add_cstride, void* dx, int dx_cstride,
+              float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+
+/* ---- aten::convolution / convolution_backward: every Convolution(conv_only=True) -> nn.Conv{2,3}d, UNet:510,557,630,650,664,
+ *      1820,1935; AEKL:67-86,121,158-187,372,454,523,606,723-749.  Per-axis (kernel,stride,padding) in {(3,1,1),(3,2,1),(1,1,0)}
+ *      (the only ones the reference's planner emits, configuration.py:751-797); anything else -> MI_ERR_UNSUPPORTED. ------------ */
+typedef struct mi_conv_plan mi_conv_plan;
+int mi_conv_plan_create(mi_conv_plan** plan, int N, int Di, int Hi, int Wi, int Cin, int Cout, const int* kernel3, const int* stride3,
+                        const int* padding3);
+int mi_conv_plan_destroy(mi_conv_plan* plan);
+int mi_conv_plan_out_dims(const mi_conv_plan* plan, int* dims3);
+/* fp32 master weight (torch layout) -> packed bf16 MFMA fragments for forward and data-gradient; call after every update */
+int mi_conv_pack_weights(mi_conv_plan* plan, const float* weight, hipStream_t stream);
+/* y = conv(act(x)) + addvec + res;  act = GroupNorm affine (+SiLU) applied on the fly when scale_shift != NULL;
+ * addvec: fp32 [Cout] (bias) or [N][Cout] (bias + time-embedding projection, UNet:692-695) */
+int mi_conv_fwd(mi_conv_plan* plan, const void* x, int x_cstride, const float* scale_shift, int silu, const float* addvec,
+                int addvec_per_n, const void* res, int res_cstride, void* y, int y_cstride, hipStream_t stream);
+/* dx = conv_transpose(dy)  (gradient w.r.t. the ACTIVATED input) */
+int mi_conv_dgrad(mi_conv_plan* plan, const void* dy, int dy_cstride, void* dx, int dx_cstride, hipStream_t stream);
+/* dweight += x_act^T * dy   (fp32, torch layout; x_act recomputed from x with the same fused prologue) */
+int mi_conv_wgrad(mi_conv_plan* plan, const void* x, int x_cstride, const float* scale_shift, int silu, const void* dy, int dy_cstride,
+                  float* dweight, hipStream_t stream);
+/* out[n][c] (+)= sum_v x[n][v][c]  (bias / time-embedding gradients) */
+int mi_colsum_bf16(const void* x, float* out, int N, int64_t V, int C, int accumulate, hipStream_t stream);
+
+/* ---- aten::mm/addmm/bmm/baddbmm + _softmax (+backward): nn.Linear (UNet:379-381,646,1832-1834), AttentionBlock._attention
+ *      (UNet:406-416, AEKL:271-281).  C[z] = alpha*A[z]*B[z]^T (+bias[n]) (+R[z]);  z -> (z/Z2, z%Z2) two-level batch strides -- */
+int mi_gemm_nt_bf16(const void* A, int lda, int64_t sA1, int64_t sA2, const void* B, int ldb, int64_t sB1, int64_t sB2, void* C, int ldc,
+                    int64_t sC1, int64_t sC2, const float* bias, const void* R, int ldr, int64_t sR1, int64_t sR2, int M, int N, int K,
+                    int Z, int Z2, float alpha, int out_f32, int accumulate, hipStream_t stream);
+int mi_transpose_bf16(const void* in, int ld_in, int64_t si1, int64_t si2, void* out, int ld_out, int64_t so1, int64_t so2, int R, int Cc,
+                      int Z, int Z2, hipStream_t stream);
+int mi_softmax_fwd(const float* scores, void* probs, int64_t rows, int cols, hipStream_t stream);
+int mi_softmax_bwd(const void* probs, const float* dprobs, void* dscores, int64_t rows, int cols, float scale, hipStream_t stream);
+
+/* ---- get_timestep_embedding (UNet:461-485), nn.SiLU on the embedding vector (UNet:1833, 692) --------------------------- */
+int mi_timestep_embedding(const int64_t* timesteps, float* out, int B, int dim, float max_period, hipStream_t stream);
+int mi_silu_f32(const float* x, float* y, int64_t n, hipStream_t stream);
+int mi_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, hipStream_t stream);
+
+/* ---- train-step glue: scheduler.add_noise (T-LDM:160), F.mse_loss (+backward) (T-LDM:169, T-DDPM:192) ------------------- */
+int mi_qsample(const float* x0, const float* noise, const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod,
+               const int64_t* timesteps, void* out, int N, int C, int64_t V, hipStream_t stream);
+int mi_mse_fwd_bwd(const void* pred, const float* target, void* dpred, float* loss, int N, int C, int64_t V, float grad_scale,
+                   hipStream_t stream);
+
+/* ---- clip_grad_norm_ (T-LDM:177, T-DDPM:196, T-AE:393,431) + torch.optim.Adam / AdamW (T-LDM:121, T-AE:470, T-DDPM:383)
+ *      over the flat fp32 parameter arena; step counter and squared norm stay on the device ------------------------------- */
+int mi_sumsq_f32(const float* x, int64_t n, float* out, int accumulate, hipStream_t stream);
+int mi_clip_grad_by_norm(float* grad, int64_t n, const float* grad_sumsq, float max_norm, hipStream_t stream);
+int mi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int decoupled_weight_decay, const float* grad_sumsq, float max_norm, float* step_counter,
+                 hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MEDIMGEN_HIP_H */

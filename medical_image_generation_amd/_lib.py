@@ -1,0 +1,116 @@
+"""ctypes binding of libmedimgen_hip.so (the C ABI declared in include/medimgen_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+PyTorch is used only as the owner of device memory and streams; every pointer handed to the
+library is `tensor.data_ptr()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmedimgen_hip.so")
+
+_p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> argtypes (return type is int unless listed in _RET)
+_SIGS = {
+    "mi_abi_version": [],
+    "mi_ncdhw_f32_to_ndhwc_bf16": [_p, _p, _i, _i, _l, _p],
+    "mi_ndhwc_bf16_to_ncdhw_f32": [_p, _p, _i, _i, _l, _p],
+    "mi_cast_f32_to_bf16": [_p, _p, _l, _p],
+    "mi_cast_bf16_to_f32": [_p, _p, _l, _i, _p],
+    "mi_add_bf16": [_p, _p, _p, _l, _p],
+    "mi_copy_channels": [_p, _i, _i, _p, _i, _i, _i, _l, _p],
+    "mi_upsample_nearest_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "mi_upsample_nearest_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "mi_space_to_depth": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "mi_depth_to_space": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "mi_gn_workspace_bytes": [_i, _l, _i],
+    "mi_gn_stats": [_p, _i, _i, _l, _i, _i, _f, _p, _p, _p, _p, _p, _l, _p],
+    "mi_gn_apply": [_p, _i, _p, _p, _i, _i, _l, _i, _i, _p],
+    "mi_gn_bwd": [_p, _i, _p, _i, _i, _l, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _l, _p],
+    "mi_conv_plan_create": [C.POINTER(_p), _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
+    "mi_conv_plan_destroy": [_p],
+    "mi_conv_plan_out_dims": [_p, C.POINTER(_i)],
+    "mi_conv_pack_weights": [_p, _p, _p],
+    "mi_conv_fwd": [_p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
+    "mi_conv_dgrad": [_p, _p, _i, _p, _i, _p],
+    "mi_conv_wgrad": [_p, _p, _i, _p, _i, _p, _i, _p, _p],
+    "mi_colsum_bf16": [_p, _p, _i, _l, _i, _i, _p],
+    "mi_gemm_nt_bf16": [_p, _i, _l, _l, _p, _i, _l, _l, _p, _i, _l, _l, _p, _p, _i, _l, _l, _i, _i, _i, _i, _i, _f, _i, _i, _p],
+    "mi_transpose_bf16": [_p, _i, _l, _l, _p, _i, _l, _l, _i, _i, _i, _i, _p],
+    "mi_softmax_fwd": [_p, _p, _l, _i, _p],
+    "mi_softmax_bwd": [_p, _p, _p, _l, _i, _f, _p],
+    "mi_timestep_embedding": [_p, _p, _i, _i, _f, _p],
+    "mi_silu_f32": [_p, _p, _l, _p],
+    "mi_silu_bwd_f32": [_p, _p, _p, _l, _p],
+    "mi_qsample": [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p],
+    "mi_mse_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _f, _p],
+    "mi_sumsq_f32": [_p, _l, _p, _i, _p],
+    "mi_clip_grad_by_norm": [_p, _l, _p, _f, _p],
+    "mi_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _p, _p],
+}
+_RET = {"mi_gn_workspace_bytes": _l}
+_NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes"}
+
+_lib = None
+
+
+def exported_symbols() -> list[str]:
+    return sorted(_SIGS)
+
+
+def load():
+    """dlopen the library (once).  Raises RuntimeError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU / PyTorch fallback for the HIP path)")
+        lib = C.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+            fn.argtypes = args
+            fn.restype = _RET.get(name, _i)
+        _lib = lib
+    return _lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_ERRS = {10001: "MI_ERR_BAD_ARG (host-side shape/alignment check failed)", 10002: "MI_ERR_UNSUPPORTED"}
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda, "medimgen HIP ops take device tensors only"
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    """Invoke `name` on the current stream (appended as the last argument) and check the status."""
+    fn = getattr(load(), name)
+    rc = fn(*args, stream_ptr())
+    if rc != 0:
+        raise HipError(f"{name} failed: {_ERRS.get(rc, f'hipError_t {rc}')}")
+
+
+def call_raw(name: str, *args):
+    fn = getattr(load(), name)
+    rc = fn(*args)
+    if name not in _NOCHECK and rc != 0:
+        raise HipError(f"{name} failed: {_ERRS.get(rc, f'hipError_t {rc}')}")
+    return rc

@@ -1,0 +1,814 @@
+// 3-D / 2-D convolution for the UNet / AutoencoderKL hot path as ONE table-driven implicit GEMM on bf16 MFMA
+// (replaces every `Convolution(conv_only=True)` -> nn.Conv{2,3}d call site: UNet:510,557,630,650,664,1820,1935; AEKL:67-86,
+// 121,158-187,372,454,523,606,723-749).
+//
+// Formulation.  Every supported convolution (per-axis (k,s,p) in {(3,1,1), (3,2,1), (1,1,0)}), its data gradient and its
+// weight gradient are instances of
+//        out[n, o, CO] (+)= sum_{chunk, tap}  Wp[CO, chunk, tap] * in[n, o + delta(tap), chunk-channels]
+// i.e. a stride-1 gather with a per-(output-channel-group, input-channel-chunk) TAP LIST:
+//   * k3 s1:       27 taps (delta in {-1,0,1}^3);      k1: one tap;
+//   * k3 s2 fwd:   runs on the space-to-depth image of x (8*Cin channels); the chunk's parity class q selects its taps
+//                  ((q=0,d=0,t=1), (q=1,d=-1,t=0), (q=1,d=0,t=2) per axis) -> exactly 27*Cin MACs per output, no waste;
+//   * dgrad s1:    the same kernel on dy with taps mirrored and the weight matrix transposed at pack time;
+//   * dgrad s2:    produces the depth image of dx (output-channel group = parity class), then depth-to-space.
+// The host-side plan (mi_conv_plan_*) builds the tables and owns the packed weights; the device code never branches on the
+// convolution type.
+//
+// Mapping to CDNA4.  GEMM view: D[co, voxel] = A[co, k] * B[k, voxel], A = packed weights, B = activations, so each lane of
+// the 32x32x16 accumulator holds 4x4 CONTIGUOUS output channels of one voxel (8-byte NDHWC stores, no transpose).
+//   * B operand: the workgroup stages a halo tile (TD+2)x(TH+2)x(TW+2) voxels x 32 channels of x in LDS ONCE per channel
+//     chunk and every tap reads it at a wave-uniform byte offset -> each activation byte is fetched ~2x from L2/HBM instead
+//     of 27x.  Voxel pitch 80 B and row pitch == 128 (mod 256) make the 4x8-voxel fragment reads (ds_read_b128)
+//     bank-conflict-free.  Staging goes through registers (issue-early / write-late) because it also applies the fused
+//     GroupNorm-affine + SiLU prologue (x*scale[n,c]+shift[n,c] -> silu) in fp32 -- the activated tensor never exists in HBM.
+//   * A operand: fragments are pre-packed in consumption order (one coalesced 1 KiB global_load_dwordx4 per fragment, served
+//     from L2 -- weights are shared by every workgroup) and double-buffered in registers across taps.
+//   * Epilogue: + (bias [+ time-embedding]) per (n, co), + residual, cast, store.
+// Weight gradient: D[co, ci] += dY^T[co, vox] * X[vox, ci]; both operands need the voxel index on the MFMA k axis, which the
+// NDHWC LDS images provide through ds_read_b64_tr_b16 (hardware transposed read); taps are distributed over the 4 waves,
+// partial sums over tile ranges go to an fp32 slab that a reduce kernel folds into the torch-layout gradient.
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+#include "medimgen_hip.h"
+
+namespace {
+
+constexpr int VOXB = 80;    // LDS bytes per voxel (32 ch * 2 B + 16 B pad)
+constexpr int KC = 32;      // channels per chunk
+
+struct Geom {           // tile + LDS geometry (host-computed, passed by value)
+  int TD, TH, TW;       // output tile (voxels); TD * (TH/4) * (TW/8) == 4 * VB
+  int hd, hh, hw;       // halo on each side per axis (0/1)
+  int HD, HH, HW;       // LDS tile dims = T + 2*halo
+  int row, slice;       // byte pitches
+  int lds_bytes;
+  int tilesD, tilesH, tilesW;
+};
+
+struct ConvArgs {
+  const bf16* x; int x_cs;
+  int N, Di, Hi, Wi, Cin;       // tensor the loader reads (already space-to-depth'ed when strided); Cin = its channel count
+  bf16* y; int y_cs; int Cout;  // channels the kernel produces (store masked to Cout)
+  int ogpq, outc_q;             // output groups (blockIdx.y) per parity class, channels per class (== ny, Cout when no classes)
+  int Do, Ho, Wo;
+  const u32x4* wpk;             // packed A fragments (64 x 16 B each)
+  const int* hdr;               // [ny][nchunks][4] = tap_begin, ntaps, src_c0, wfrag_begin
+  const int* taps;              // LDS byte offsets
+  int nchunks;
+  const float* ss; int ss_C; int pro_silu;  // prologue affine [N][ss_C][2] (channel = src channel % ss_C) or null
+  const float* addvec; int addvec_per_n;    // [N][Cout] / [Cout] fp32 or null
+  const bf16* res; int res_cs;
+  Geom g;
+};
+
+// ------------------------------------------------------------------------------------------------ halo staging
+template <int NP>
+struct Stage {
+  int goff[NP];   // element offset of the voxel in x (without channel), -1 = outside / unused
+  int loff[NP];   // LDS byte offset
+  u32x4 pre[NP];
+};
+
+template <int NP>
+__device__ __forceinline__ void stage_setup(Stage<NP>& s, const ConvArgs& a, int n, int d0, int h0, int w0) {
+  const Geom& g = a.g;
+  const int HVOX = g.HD * g.HH * g.HW;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    int pc = threadIdx.x + 256 * i;
+    int v = pc >> 2, part = pc & 3;
+    int hdz = v / (g.HH * g.HW);
+    int rem = v - hdz * (g.HH * g.HW);
+    int hhz = rem / g.HW, hwz = rem - hhz * g.HW;
+    int gd = d0 - g.hd + hdz, gh = h0 - g.hh + hhz, gw = w0 - g.hw + hwz;
+    bool ok = v < HVOX && gd >= 0 && gd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi;
+    s.goff[i] = ok ? (((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) : -1;
+    s.loff[i] = v < HVOX ? hdz * g.slice + hhz * g.row + hwz * VOXB + part * 16 : -1;
+  }
+}
+
+template <int NP>
+__device__ __forceinline__ void stage_load(Stage<NP>& s, const ConvArgs& a, int src_c0) {
+  const int part = threadIdx.x & 3;
+  const int c = src_c0 + part * 8;
+  const bool vec = ((a.x_cs & 7) == 0) && (c + 8 <= a.Cin);
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (s.goff[i] >= 0) {
+      const bf16* p = a.x + (int64_t)s.goff[i] * a.x_cs + c;
+      if (vec) {
+        v = *(const u32x4*)p;
+      } else {  // ragged channel counts (Cin = 1, 4, ...): element-wise with masking
+        F8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.v[j] = (c + j < a.Cin) ? bf2f(p[j]) : 0.f;
+        v = pack8(f);
+      }
+    }
+    s.pre[i] = v;
+  }
+}
+
+template <int NP>
+__device__ __forceinline__ void stage_store(Stage<NP>& s, const ConvArgs& a, int n, int src_c0, char* lds) {
+  const int part = threadIdx.x & 3;
+  float sc[8], sh[8];
+  if (a.ss) {
+    const int c = (src_c0 % a.ss_C) + part * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      bool in = c + j < a.ss_C;
+      sc[j] = in ? a.ss[((int64_t)n * a.ss_C + c + j) * 2] : 0.f;
+      sh[j] = in ? a.ss[((int64_t)n * a.ss_C + c + j) * 2 + 1] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (s.loff[i] < 0) continue;
+    u32x4 v = s.pre[i];
+    if (a.ss && s.goff[i] >= 0) {  // zero padding stays zero: the reference pads AFTER norm+activation
+      F8 f = unpack8(v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float u = f.v[j] * sc[j] + sh[j];
+        f.v[j] = a.pro_silu ? silu_f(u) : u;
+      }
+      v = pack8(f);
+    }
+    *(u32x4*)(lds + s.loff[i]) = v;
+  }
+}
+
+__device__ __forceinline__ void tile_origin(const Geom& g, int tile, int& n, int& d0, int& h0, int& w0) {
+  int tw = tile % g.tilesW; tile /= g.tilesW;
+  int th = tile % g.tilesH; tile /= g.tilesH;
+  int td = tile % g.tilesD;
+  n = tile / g.tilesD;
+  d0 = td * g.TD; h0 = th * g.TH; w0 = tw * g.TW;
+}
+
+// voxel block b (32 voxels = 4 rows x 8 cols of one slice) -> tile-relative (d, h, w) of its corner
+__device__ __forceinline__ void block_origin(const Geom& g, int b, int& bd, int& bh, int& bw) {
+  const int bpw = g.TW / 8, bph = g.TH / 4;
+  bw = (b % bpw) * 8;
+  bh = ((b / bpw) % bph) * 4;
+  bd = b / (bpw * bph);
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad kernel
+template <int NCB, int VB, int NP>
+__global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const Geom& g = a.g;
+  int n, d0, h0, w0;
+  tile_origin(g, blockIdx.x, n, d0, h0, w0);
+  const int y = blockIdx.y;
+
+  Stage<NP> st;
+  stage_setup<NP>(st, a, n, d0, h0, w0);
+
+  int bbase[VB];  // LDS byte address of this lane's voxel (tile-relative, halo origin added through the tap offsets)
+  int od[VB], oh[VB], ow[VB];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb) {
+    int bd, bh, bw;
+    block_origin(g, wave * VB + vb, bd, bh, bw);
+    int vh = bh + (r >> 3), vw = bw + (r & 7);
+    bbase[vb] = bd * g.slice + vh * g.row + vw * VOXB + h * 16;
+    od[vb] = d0 + bd; oh[vb] = h0 + vh; ow[vb] = w0 + vw;
+  }
+
+  f32x16 acc[VB][NCB];
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[vb][cb][e] = 0.f;
+
+  const int* hdr = a.hdr + (int64_t)y * a.nchunks * 4;
+  stage_load<NP>(st, a, hdr[2]);
+  for (int ch = 0; ch < a.nchunks; ++ch) {
+    const int tap_begin = hdr[ch * 4 + 0], ntaps = hdr[ch * 4 + 1], src_c0 = hdr[ch * 4 + 2], wfrag = hdr[ch * 4 + 3];
+    __syncthreads();  // every wave is done reading the previous chunk's tile
+    stage_store<NP>(st, a, n, src_c0, lds);
+    __syncthreads();
+    if (ch + 1 < a.nchunks) stage_load<NP>(st, a, hdr[(ch + 1) * 4 + 2]);  // in flight under the MFMAs below
+
+    const u32x4* wp = a.wpk + (int64_t)wfrag * 64 + lane;
+    u32x4 wa[2][NCB], wn[2][NCB];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) wa[ks][cb] = wp[(ks * NCB + cb) * 64];
+    for (int t = 0; t < ntaps; ++t) {
+      if (t + 1 < ntaps) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) wn[ks][cb] = wp[(((t + 1) * 2 + ks) * NCB + cb) * 64];
+      }
+      const int toff = a.taps[tap_begin + t];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int vb = 0; vb < VB; ++vb) {
+          bf16x8 fb = *(const bf16x8*)(lds + bbase[vb] + toff + ks * 32);
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+            acc[vb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[ks][cb]), fb, acc[vb][cb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) wa[ks][cb] = wn[ks][cb];
+    }
+  }
+
+  // epilogue: lane holds voxel r of each block, channels co_base + 8*grp + 4*h + (0..3) for grp = 0..3
+  const int cls = y / a.ogpq, cls_base = cls * a.outc_q, cls_lim = cls_base + a.outc_q;
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb) {
+    if (od[vb] >= a.Do || oh[vb] >= a.Ho || ow[vb] >= a.Wo) continue;
+    const int64_t vox = ((int64_t)(n * a.Do + od[vb]) * a.Ho + oh[vb]) * a.Wo + ow[vb];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+      for (int grp = 0; grp < 4; ++grp) {
+        const int co = cls_base + ((y - cls * a.ogpq) * NCB + cb) * 32 + grp * 8 + h * 4;
+        if (co >= cls_lim) continue;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[vb][cb][grp * 4 + i];
+        const bool full = (co + 4 <= cls_lim) && ((a.y_cs & 3) == 0);
+        if (a.addvec) {
+          const float* av = a.addvec + (a.addvec_per_n ? (int64_t)n * a.Cout : 0) + co;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (co + i < cls_lim) v[i] += av[i];
+        }
+        if (a.res) {
+          const bf16* rp = a.res + vox * a.res_cs + co;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (co + i < cls_lim) v[i] += bf2f(rp[i]);
+        }
+        bf16* yp = a.y + vox * a.y_cs + co;
+        if (full) {
+          u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+          *(u32x2*)yp = o;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (co + i < cls_lim) yp[i] = f2bf(v[i]);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight-gradient kernel
+struct WgradArgs {
+  ConvArgs c;         // x side: loader geometry / tables (NCB = 1 tables); y/res/addvec unused
+  const bf16* dy; int dy_cs;
+  float* part;        // [nsplit][npairs][MAXTAPS? -> ntaps_of_pair][32][32] laid out by pair_off
+  const int* pair_off;  // [npairs] float offset of the pair's slab inside one split's partial
+  int64_t split_stride; // floats per split
+  int ntiles, nsplit;
+};
+
+__device__ __forceinline__ bf16x8 tr_read16(const char* base) {
+  // two ds_read_b64_tr_b16: 4 voxels x 16 channels each, delivered channel-per-lane (see header comment)
+  typedef __attribute__((address_space(3))) bf16x4 lds_v4;
+  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(base));
+  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(base + 4 * VOXB));
+  bf16x8 f;
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
+  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+  return f;
+}
+
+template <int NP, int NPY, int MAXT>
+__global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const ConvArgs& a = w.c;
+  const Geom& g = a.g;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  char* ldy = lds + g.lds_bytes;  // dY tile: [TD][TH][TW] voxels x 32 co, pitch VOXB, row pitch TW*VOXB
+  const int pair = blockIdx.x;    // (y, chunk)
+  const int y = pair / a.nchunks;
+  const int* hdr = a.hdr + (int64_t)pair * 4;
+  const int tap_begin = hdr[0], ntaps = hdr[1], src_c0 = hdr[2];
+
+  // transposed-read lane roles: 16-lane group gq -> channel half (gq&1), k half (gq>>1); lane 4q+p -> voxel row q, chan 4p
+  const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int kh = gq >> 1;                       // which of the 2 h-rows of the k-step
+  const int chan_b = ((gq & 1) * 16 + pp * 4) * 2;  // byte offset of the 4-channel piece inside the voxel
+
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  int toff[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    int ti = wave + 4 * t;
+    toff[t] = ti < ntaps ? a.taps[tap_begin + ti] : -1;
+  }
+  const int dyrow = g.TW * VOXB, dyslice = g.TH * dyrow;
+  const int NVOX = g.TD * g.TH * g.TW;
+
+  for (int tile = blockIdx.y; tile < w.ntiles; tile += w.nsplit) {
+    int n, d0, h0, w0;
+    tile_origin(g, tile, n, d0, h0, w0);
+    Stage<NP> st;
+    stage_setup<NP>(st, a, n, d0, h0, w0);
+    stage_load<NP>(st, a, src_c0);
+    // dY tile -> registers
+    u32x4 py[NPY];
+    int pyoff[NPY];
+#pragma unroll
+    for (int i = 0; i < NPY; ++i) {
+      int pc = threadIdx.x + 256 * i;
+      int v = pc >> 2, part = pc & 3;
+      int vd = v / (g.TH * g.TW), rem = v - vd * (g.TH * g.TW);
+      int vh = rem / g.TW, vw = rem - vh * g.TW;
+      int od = d0 + vd, oh = h0 + vh, ow = w0 + vw;
+      int co = y * 32 + part * 8;
+      u32x4 val = {0u, 0u, 0u, 0u};
+      pyoff[i] = v < NVOX ? vd * dyslice + vh * dyrow + vw * VOXB + part * 16 : -1;
+      if (v < NVOX && od < a.Do && oh < a.Ho && ow < a.Wo && co < a.Cout) {
+        const bf16* p = w.dy + ((int64_t)((n * a.Do + od) * a.Ho + oh) * a.Wo + ow) * w.dy_cs + co;
+        if (co + 8 <= a.Cout && (w.dy_cs & 7) == 0) {
+          val = *(const u32x4*)p;
+        } else {
+          F8 f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) f.v[j] = (co + j < a.Cout) ? bf2f(p[j]) : 0.f;
+          val = pack8(f);
+        }
+      }
+      py[i] = val;
+    }
+    __syncthreads();  // previous tile fully consumed
+    stage_store<NP>(st, a, n, src_c0, lds);
+#pragma unroll
+    for (int i = 0; i < NPY; ++i)
+      if (pyoff[i] >= 0) *(u32x4*)(ldy + pyoff[i]) = py[i];
+    __syncthreads();
+
+    // k-steps: 16 voxels = 2 h-rows x 8 w of one slice
+    const int ksteps = g.TD * (g.TH / 2) * (g.TW / 8);
+    for (int s = 0; s < ksteps; ++s) {
+      int sw = (s % (g.TW / 8)) * 8;
+      int sh = ((s / (g.TW / 8)) % (g.TH / 2)) * 2;
+      int sd = s / ((g.TW / 8) * (g.TH / 2));
+      // lane address for voxel (sd, sh + kh, sw + q) [+4 voxels for the second read], channel piece chan_b
+      const char* ya = ldy + sd * dyslice + (sh + kh) * dyrow + (sw + q) * VOXB + chan_b;
+      bf16x8 fa = tr_read16(ya);
+      const char* xa = lds + sd * g.slice + (sh + kh) * g.row + (sw + q) * VOXB + chan_b;
+#pragma unroll
+      for (int t = 0; t < MAXT; ++t) {
+        if (toff[t] < 0) continue;  // wave-uniform
+        bf16x8 fb = tr_read16(xa + toff[t]);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+      }
+    }
+  }
+
+  // partial slab: [tap][co 32][ci 32]; D map: col = lane&31 -> ci, row -> co
+  float* out = w.part + (int64_t)blockIdx.y * w.split_stride + w.pair_off[pair];
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    int ti = wave + 4 * t;
+    if (ti >= ntaps) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int co = (e & 3) + 8 * (e >> 2) + 4 * h;
+      out[((int64_t)ti * 32 + co) * 32 + r] = acc[t][e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight pack / unpack
+// frag_items[f] = {src_tap, co0, ci0, flags}: fragment f holds A[row = co0 + r][k = ci0 + 8h + j] (kernel channel indices);
+// torch weight W[Co_t][Ci_t][KT]; flags bit0: transposed (kernel-out = torch-in), i.e. dgrad.
+__global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, u32x4* __restrict__ out,
+                                                      const int* __restrict__ items, int nfrags, int Co_t, int Ci_t, int KT) {
+  int gid = blockIdx.x * 256 + threadIdx.x;
+  int f = gid >> 6, lane = gid & 63;
+  if (f >= nfrags) return;
+  const int* it = items + f * 4;
+  int tap = it[0], co = it[1] + (lane & 31), ci0 = it[2] + (lane >> 5) * 8, tr = it[3] & 1;
+  F8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    int ci = ci0 + j;
+    int o = tr ? ci : co, i = tr ? co : ci;  // torch (out, in) indices
+    v.v[j] = (tap >= 0 && o < Co_t && i < Ci_t) ? w[((int64_t)o * Ci_t + i) * KT + tap] : 0.f;
+  }
+  out[gid] = pack8(v);
+}
+
+// dW[co][ci][tap] += sum_split part[split][pair][ti][co_l][ci_l];  uitems[(pair, ti)] = {src_tap, co0, ci0, _}
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, int64_t split_stride, int nsplit,
+                                                      const int* __restrict__ uitems, int nitems, float* __restrict__ dw, int Co_t,
+                                                      int Ci_t, int KT) {
+  int64_t gid = blockIdx.x * 256ll + threadIdx.x;
+  int item = (int)(gid >> 10), e = (int)(gid & 1023);
+  if (item >= nitems) return;
+  const int* it = uitems + item * 4;
+  int tap = it[0], co = it[1] + (e >> 5), ci = it[2] + (e & 31);
+  if (tap < 0 || co >= Co_t || ci >= Ci_t) return;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += part[k * split_stride + (int64_t)item * 1024 + e];
+  dw[((int64_t)co * Ci_t + ci) * KT + tap] += s;
+}
+
+// ------------------------------------------------------------------------------------------------ host-side plan
+struct AxisCombo { int q, delta, t; };
+
+struct Tables {
+  std::vector<int> hdr, taps, frag_items;  // kernel tables + pack items
+  int ny = 0, nchunks = 0, nfrags = 0;
+  int* d_hdr = nullptr; int* d_taps = nullptr; int* d_items = nullptr;
+  u32x4* d_wpk = nullptr;
+};
+
+int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+Geom make_geom(int VB, int Do, int Ho, int Wo, const int halo[3], int N) {
+  Geom g;
+  // tile = 4*VB blocks of 4x8 voxels (VB blocks per wave); single-slice volumes (2-D nets) put all blocks in one slice
+  if (Do == 1) { g.TD = 1; g.TH = 16; g.TW = 8 * VB; }
+  else { g.TD = 2 * VB; g.TH = 8; g.TW = 8; }
+  g.hd = halo[0]; g.hh = halo[1]; g.hw = halo[2];
+  g.HD = g.TD + 2 * g.hd; g.HH = g.TH + 2 * g.hh; g.HW = g.TW + 2 * g.hw;
+  int row = g.HW * VOXB;
+  int rr = rup(row, 256) + 128;           // == 128 (mod 256), >= row  (may overshoot by < 256)
+  if (rr - 256 >= row) rr -= 256;
+  g.row = rr;
+  g.slice = g.HH * g.row;
+  g.lds_bytes = g.HD * g.slice;
+  g.tilesD = (Do + g.TD - 1) / g.TD; g.tilesH = (Ho + g.TH - 1) / g.TH; g.tilesW = (Wo + g.TW - 1) / g.TW;
+  (void)N;
+  return g;
+}
+
+}  // namespace
+
+struct mi_conv_plan {
+  int N, Di, Hi, Wi, Cin, Cout, k[3], s[3], p[3];
+  int Do, Ho, Wo;
+  int f[3], Q;            // space-to-depth factors of x for strided axes
+  int Dp, Hp, Wp;         // depth-side dims of x (== Do.. for supported (k,s,p))
+  int KT;
+  int ncb_fwd, ncb_dg;
+  Geom g_fwd, g_dg, g_wg;
+  Tables fwd, dg, wg;     // wg: NCB = 1 tables on the fwd geometry (weights unused)
+  std::vector<int> wg_pair_off, wg_uitems;
+  int* d_pair_off = nullptr; int* d_uitems = nullptr;
+  int64_t wg_split_stride = 0; int wg_nsplit = 0, wg_nitems = 0;
+  float* d_part = nullptr;
+  bf16* d_xs = nullptr;   // space-to-depth image of x (strided convs)
+  bf16* d_dxs = nullptr;  // depth image of dx
+  bool strided = false;
+};
+
+namespace {
+
+bool axis_combos_fwd(int k, int s, int p, std::vector<AxisCombo>& out, int& f) {
+  out.clear();
+  if (k == 3 && s == 1 && p == 1) { f = 1; for (int t = 0; t < 3; ++t) out.push_back({0, t - 1, t}); return true; }
+  if (k == 1 && s == 1 && p == 0) { f = 1; out.push_back({0, 0, 0}); return true; }
+  if (k == 3 && s == 2 && p == 1) { f = 2; out.push_back({0, 0, 1}); out.push_back({1, -1, 0}); out.push_back({1, 0, 2}); return true; }
+  return false;
+}
+// dgrad: dx-depth[j][q] = sum W[t]^T dy[j + delta]
+bool axis_combos_dgrad(int k, int s, int p, std::vector<AxisCombo>& out) {
+  out.clear();
+  if (k == 3 && s == 1 && p == 1) { for (int t = 0; t < 3; ++t) out.push_back({0, 1 - t, t}); return true; }
+  if (k == 1 && s == 1 && p == 0) { out.push_back({0, 0, 0}); return true; }
+  if (k == 3 && s == 2 && p == 1) { out.push_back({0, 0, 1}); out.push_back({1, 1, 0}); out.push_back({1, 0, 2}); return true; }
+  return false;
+}
+
+int tap_lds_off(const Geom& g, int dd, int dh, int dw) {
+  return (dd + g.hd) * g.slice + (dh + g.hh) * g.row + (dw + g.hw) * VOXB;
+}
+
+// Build tables for:  out channels = OutC (grouped in blocks of 32*NCB; group -> (qo, co-block) when out is a depth image),
+// in channels = InC per parity class qi.  `combos[axis]` lists (q, delta, t); `q_on_input` tells whether q partitions the
+// INPUT channels (fwd on s2d image) or the OUTPUT channels (dgrad producing a depth image).
+void build_tables(Tables& T, const Geom& g, int NCB, const std::vector<AxisCombo> combos[3], const int f[3], const int k[3], bool q_on_input,
+                  int InC, int OutC, bool transposed) {
+  const int Q = f[0] * f[1] * f[2];
+  const int in_chunks_per_q = (InC + KC - 1) / KC;
+  const int out_groups_per_q = (OutC + 32 * NCB - 1) / (32 * NCB);
+  T.nchunks = q_on_input ? Q * in_chunks_per_q : in_chunks_per_q;
+  T.ny = q_on_input ? out_groups_per_q : Q * out_groups_per_q;
+  T.hdr.assign((size_t)T.ny * T.nchunks * 4, 0);
+  T.taps.clear(); T.frag_items.clear();
+  int nfrag = 0;
+  for (int y = 0; y < T.ny; ++y)
+    for (int ch = 0; ch < T.nchunks; ++ch) {
+      int q = q_on_input ? ch / in_chunks_per_q : y / out_groups_per_q;
+      int cin0 = (q_on_input ? ch % in_chunks_per_q : ch) * KC;   // kernel-input channel within the class
+      int cog = q_on_input ? y : y % out_groups_per_q;
+      int qd = q / (f[1] * f[2]), qh = (q / f[2]) % f[1], qw = q % f[2];
+      int* H = &T.hdr[((size_t)y * T.nchunks + ch) * 4];
+      H[0] = (int)T.taps.size();
+      H[2] = q_on_input ? q * InC + cin0 : cin0;  // source channel offset in the tensor the loader reads
+      H[3] = nfrag;
+      int nt = 0;
+      for (auto& cd : combos[0]) { if (cd.q != qd) continue;
+        for (auto& chh : combos[1]) { if (chh.q != qh) continue;
+          for (auto& cw : combos[2]) { if (cw.q != qw) continue;
+            T.taps.push_back(tap_lds_off(g, cd.delta, chh.delta, cw.delta));
+            int src_tap = (cd.t * k[1] + chh.t) * k[2] + cw.t;
+            for (int ks = 0; ks < 2; ++ks)
+              for (int cb = 0; cb < NCB; ++cb) {
+                T.frag_items.push_back(src_tap);
+                T.frag_items.push_back((cog * NCB + cb) * 32);
+                T.frag_items.push_back(cin0 + ks * 16);
+                T.frag_items.push_back(transposed ? 1 : 0);
+                ++nfrag;
+              }
+            ++nt;
+          } } }
+      H[1] = nt;
+    }
+  T.nfrags = nfrag;
+}
+
+int upload(const std::vector<int>& v, int** d) {
+  size_t bytes = (v.size() ? v.size() : 1) * sizeof(int);
+  hipError_t e = hipMalloc((void**)d, bytes);
+  if (e != hipSuccess) return (int)e;
+  if (v.size()) e = hipMemcpy(*d, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice);
+  return (int)e;
+}
+int upload_tables(Tables& T, bool with_weights) {
+  int e;
+  if ((e = upload(T.hdr, &T.d_hdr))) return e;
+  if ((e = upload(T.taps, &T.d_taps))) return e;
+  if ((e = upload(T.frag_items, &T.d_items))) return e;
+  if (with_weights) {
+    hipError_t he = hipMalloc((void**)&T.d_wpk, (size_t)(T.nfrags ? T.nfrags : 1) * 1024);
+    if (he != hipSuccess) return (int)he;
+  }
+  return 0;
+}
+void free_tables(Tables& T) {
+  if (T.d_hdr) (void)hipFree(T.d_hdr);
+  if (T.d_taps) (void)hipFree(T.d_taps);
+  if (T.d_items) (void)hipFree(T.d_items);
+  if (T.d_wpk) (void)hipFree(T.d_wpk);
+}
+
+template <int NCB, int VB>
+int launch_igemm(const ConvArgs& a, int ntiles, int ny, hipStream_t st) {
+  const int hv = a.g.HD * a.g.HH * a.g.HW;
+  const int np = (hv * 4 + 255) / 256;
+  dim3 grid(ntiles, ny), blk(256);
+  size_t lds = (size_t)a.g.lds_bytes;
+#define MI_LAUNCH_NP(NPV)                                                                                  \
+  do {                                                                                                     \
+    auto kern = k_conv_igemm<NCB, VB, NPV>;                                                                \
+    if (lds > 48 * 1024) {                                                                                 \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                                  \
+    }                                                                                                      \
+    hipLaunchKernelGGL(kern, grid, blk, lds, st, a);                                                       \
+  } while (0)
+  if (np <= 4) MI_LAUNCH_NP(4);
+  else if (np <= 6) MI_LAUNCH_NP(6);
+  else if (np <= 10) MI_LAUNCH_NP(10);
+  else if (np <= 16) MI_LAUNCH_NP(16);
+  else return MI_ERR_BAD_ARG;
+#undef MI_LAUNCH_NP
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+int launch_igemm_any(const ConvArgs& a, int NCB, int ntiles, int ny, hipStream_t st) {
+  if (NCB == 2) return launch_igemm<2, 2>(a, ntiles, ny, st);
+  return launch_igemm<1, 2>(a, ntiles, ny, st);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int Cin, int Cout, const int* k, const int* s, const int* p) {
+  if (!out || N <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Cin <= 0 || Cout <= 0) return MI_ERR_BAD_ARG;
+  mi_conv_plan* P = new mi_conv_plan();
+  P->N = N; P->Di = Di; P->Hi = Hi; P->Wi = Wi; P->Cin = Cin; P->Cout = Cout;
+  std::vector<AxisCombo> cf[3], cdg[3];
+  int dims[3] = {Di, Hi, Wi}, od[3], halo_f[3] = {0, 0, 0}, halo_d[3] = {0, 0, 0};
+  for (int a = 0; a < 3; ++a) {
+    P->k[a] = k[a]; P->s[a] = s[a]; P->p[a] = p[a];
+    if (!axis_combos_fwd(k[a], s[a], p[a], cf[a], P->f[a]) || !axis_combos_dgrad(k[a], s[a], p[a], cdg[a])) {
+      delete P;
+      return MI_ERR_UNSUPPORTED;
+    }
+    od[a] = (dims[a] + 2 * p[a] - k[a]) / s[a] + 1;
+    for (auto& c : cf[a]) if (c.delta != 0) halo_f[a] = 1;
+    for (auto& c : cdg[a]) if (c.delta != 0) halo_d[a] = 1;
+  }
+  P->Do = od[0]; P->Ho = od[1]; P->Wo = od[2];
+  P->Q = P->f[0] * P->f[1] * P->f[2];
+  P->strided = P->Q > 1;
+  P->Dp = (Di + P->f[0] - 1) / P->f[0]; P->Hp = (Hi + P->f[1] - 1) / P->f[1]; P->Wp = (Wi + P->f[2] - 1) / P->f[2];
+  P->KT = k[0] * k[1] * k[2];
+  if (P->strided && (Cin % KC) != 0) { delete P; return MI_ERR_UNSUPPORTED; }  // parity classes must align with 32-channel chunks
+  P->ncb_fwd = Cout > 32 ? 2 : 1;
+  P->ncb_dg = Cin > 32 ? 2 : 1;
+  // forward: loader reads x (or its depth image: dims Dp.., Q*Cin channels); outputs on the (Do,Ho,Wo) grid
+  P->g_fwd = make_geom(2, P->Do, P->Ho, P->Wo, halo_f, N);
+  build_tables(P->fwd, P->g_fwd, P->ncb_fwd, cf, P->f, P->k, true, Cin, Cout, false);
+  // dgrad: loader reads dy (Do,Ho,Wo,Cout); outputs the depth image of dx on the (Dp,Hp,Wp) grid with Q*Cin channels
+  P->g_dg = make_geom(2, P->Dp, P->Hp, P->Wp, halo_d, N);
+  build_tables(P->dg, P->g_dg, P->ncb_dg, cdg, P->f, P->k, false, Cout, Cin, true);
+  // wgrad: forward geometry, 32-cout groups
+  P->g_wg = P->g_fwd;
+  build_tables(P->wg, P->g_wg, 1, cf, P->f, P->k, true, Cin, Cout, false);
+  int e;
+  if ((e = upload_tables(P->fwd, true)) || (e = upload_tables(P->dg, true)) || (e = upload_tables(P->wg, false))) { mi_conv_plan_destroy(P); return e; }
+  // wgrad partial slabs: per pair, ntaps * 1024 floats
+  int npairs = P->wg.ny * P->wg.nchunks;
+  int64_t off = 0;
+  P->wg_pair_off.resize(npairs);
+  for (int pr = 0; pr < npairs; ++pr) {
+    P->wg_pair_off[pr] = (int)off;
+    int nt = P->wg.hdr[(size_t)pr * 4 + 1];
+    int frag0 = P->wg.hdr[(size_t)pr * 4 + 3];
+    for (int t = 0; t < nt; ++t) {  // item = first fragment (ks = 0, cb = 0) of the tap
+      const int* it = &P->wg.frag_items[(size_t)(frag0 + t * 2) * 4];
+      P->wg_uitems.push_back(it[0]); P->wg_uitems.push_back(it[1]); P->wg_uitems.push_back(it[2]); P->wg_uitems.push_back(0);
+    }
+    off += (int64_t)nt * 1024;
+  }
+  P->wg_split_stride = off;
+  P->wg_nitems = (int)(off / 1024);
+  int ntiles = N * P->g_wg.tilesD * P->g_wg.tilesH * P->g_wg.tilesW;
+  int nsplit = (1024 + npairs - 1) / npairs;           // aim at ~1024 workgroups
+  if (nsplit > ntiles) nsplit = ntiles;
+  while (nsplit > 1 && (int64_t)nsplit * off * 4 > (256ll << 20)) nsplit /= 2;  // cap the slab at 256 MiB
+  if (nsplit < 1) nsplit = 1;
+  P->wg_nsplit = nsplit;
+  if ((e = upload(P->wg_pair_off, &P->d_pair_off)) || (e = upload(P->wg_uitems, &P->d_uitems))) { mi_conv_plan_destroy(P); return e; }
+  if (hipMalloc((void**)&P->d_part, (size_t)nsplit * off * 4) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
+  if (P->strided) {
+    size_t nb = (size_t)N * P->Dp * P->Hp * P->Wp * P->Q * Cin * 2;
+    if (hipMalloc((void**)&P->d_xs, nb) != hipSuccess || hipMalloc((void**)&P->d_dxs, nb) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
+  }
+  *out = P;
+  return 0;
+}
+
+int mi_conv_plan_destroy(mi_conv_plan* P) {
+  if (!P) return 0;
+  free_tables(P->fwd); free_tables(P->dg); free_tables(P->wg);
+  if (P->d_pair_off) (void)hipFree(P->d_pair_off);
+  if (P->d_uitems) (void)hipFree(P->d_uitems);
+  if (P->d_part) (void)hipFree(P->d_part);
+  if (P->d_xs) (void)hipFree(P->d_xs);
+  if (P->d_dxs) (void)hipFree(P->d_dxs);
+  delete P;
+  return 0;
+}
+
+int mi_conv_plan_out_dims(const mi_conv_plan* P, int* dims3) {
+  if (!P || !dims3) return MI_ERR_BAD_ARG;
+  dims3[0] = P->Do; dims3[1] = P->Ho; dims3[2] = P->Wo;
+  return 0;
+}
+
+// fp32 master weight [Cout][Cin][kd][kh][kw] -> packed bf16 fragments for forward and dgrad
+int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
+  if (!P || !w) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_pack_weights, dim3((P->fwd.nfrags * 64 + 255) / 256), dim3(256), 0, st, w, P->fwd.d_wpk, P->fwd.d_items, P->fwd.nfrags,
+                     P->Cout, P->Cin, P->KT);
+  hipLaunchKernelGGL(k_pack_weights, dim3((P->dg.nfrags * 64 + 255) / 256), dim3(256), 0, st, w, P->dg.d_wpk, P->dg.d_items, P->dg.nfrags,
+                     P->Cout, P->Cin, P->KT);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const float* addvec, int addvec_per_n,
+                const void* res, int res_cs, void* y, int y_cs, hipStream_t st) {
+  if (!P || !x || !y || x_cs < P->Cin || y_cs < P->Cout) return MI_ERR_BAD_ARG;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  const bf16* src = (const bf16*)x;
+  int src_cs = x_cs;
+  if (P->strided) {
+    if (x_cs != P->Cin) return MI_ERR_UNSUPPORTED;
+    int e = mi_space_to_depth(x, P->d_xs, P->N, P->Di, P->Hi, P->Wi, P->Cin, P->f[0], P->f[1], P->f[2], st);
+    if (e) return e;
+    src = P->d_xs;
+    src_cs = P->Q * P->Cin;
+  }
+  a.x = src; a.x_cs = src_cs; a.N = P->N; a.Di = P->Dp; a.Hi = P->Hp; a.Wi = P->Wp; a.Cin = P->strided ? P->Q * P->Cin : P->Cin;
+  if (!P->strided) { a.Di = P->Di; a.Hi = P->Hi; a.Wi = P->Wi; }
+  a.y = (bf16*)y; a.y_cs = y_cs; a.Cout = P->Cout; a.Do = P->Do; a.Ho = P->Ho; a.Wo = P->Wo;
+  a.ogpq = P->fwd.ny; a.outc_q = P->Cout;
+  a.wpk = P->fwd.d_wpk; a.hdr = P->fwd.d_hdr; a.taps = P->fwd.d_taps; a.nchunks = P->fwd.nchunks;
+  a.ss = scale_shift; a.ss_C = P->Cin; a.pro_silu = silu;
+  a.addvec = addvec; a.addvec_per_n = addvec_per_n;
+  a.res = (const bf16*)res; a.res_cs = res_cs;
+  a.g = P->g_fwd;
+  int ntiles = P->N * a.g.tilesD * a.g.tilesH * a.g.tilesW;
+  return launch_igemm_any(a, P->ncb_fwd, ntiles, P->fwd.ny, st);
+}
+
+int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_cs, hipStream_t st) {
+  if (!P || !dy || !dx || dy_cs < P->Cout || dx_cs < P->Cin) return MI_ERR_BAD_ARG;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const bf16*)dy; a.x_cs = dy_cs; a.N = P->N; a.Di = P->Do; a.Hi = P->Ho; a.Wi = P->Wo; a.Cin = P->Cout;
+  a.Do = P->Dp; a.Ho = P->Hp; a.Wo = P->Wp;
+  a.Cout = P->Q * P->Cin;
+  a.ogpq = P->dg.ny / P->Q; a.outc_q = P->Cin;
+  if (P->strided) {
+    if (dx_cs != P->Cin) return MI_ERR_UNSUPPORTED;
+    a.y = P->d_dxs; a.y_cs = P->Q * P->Cin;
+  } else {
+    a.y = (bf16*)dx; a.y_cs = dx_cs;
+  }
+  a.wpk = P->dg.d_wpk; a.hdr = P->dg.d_hdr; a.taps = P->dg.d_taps; a.nchunks = P->dg.nchunks;
+  a.g = P->g_dg;
+  int ntiles = P->N * a.g.tilesD * a.g.tilesH * a.g.tilesW;
+  int e = launch_igemm_any(a, P->ncb_dg, ntiles, P->dg.ny, st);
+  if (e) return e;
+  if (P->strided) return mi_depth_to_space(P->d_dxs, dx, P->N, P->Di, P->Hi, P->Wi, P->Cin, P->f[0], P->f[1], P->f[2], st);
+  return 0;
+}
+
+// dw (fp32, torch layout [Cout][Cin][kd][kh][kw]) += wgrad;  x side takes the same fused prologue as the forward
+int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const void* dy, int dy_cs, float* dw,
+                  hipStream_t st) {
+  if (!P || !x || !dy || !dw || x_cs < P->Cin || dy_cs < P->Cout) return MI_ERR_BAD_ARG;
+  WgradArgs w;
+  memset(&w, 0, sizeof(w));
+  ConvArgs& a = w.c;
+  const bf16* src = (const bf16*)x;
+  int src_cs = x_cs;
+  if (P->strided) {
+    if (x_cs != P->Cin) return MI_ERR_UNSUPPORTED;
+    int e = mi_space_to_depth(x, P->d_xs, P->N, P->Di, P->Hi, P->Wi, P->Cin, P->f[0], P->f[1], P->f[2], st);
+    if (e) return e;
+    src = P->d_xs;
+    src_cs = P->Q * P->Cin;
+  }
+  a.x = src; a.x_cs = src_cs; a.N = P->N;
+  a.Di = P->strided ? P->Dp : P->Di; a.Hi = P->strided ? P->Hp : P->Hi; a.Wi = P->strided ? P->Wp : P->Wi;
+  a.Cin = P->strided ? P->Q * P->Cin : P->Cin;
+  a.Cout = P->Cout; a.Do = P->Do; a.Ho = P->Ho; a.Wo = P->Wo;
+  a.hdr = P->wg.d_hdr; a.taps = P->wg.d_taps; a.nchunks = P->wg.nchunks;
+  a.ss = scale_shift; a.ss_C = P->Cin; a.pro_silu = silu;
+  a.g = P->g_wg;
+  w.dy = (const bf16*)dy; w.dy_cs = dy_cs;
+  w.part = P->d_part; w.pair_off = P->d_pair_off; w.split_stride = P->wg_split_stride;
+  w.ntiles = P->N * a.g.tilesD * a.g.tilesH * a.g.tilesW;
+  w.nsplit = P->wg_nsplit;
+  const int hv = a.g.HD * a.g.HH * a.g.HW;
+  const int np = (hv * 4 + 255) / 256;
+  const int nvox = a.g.TD * a.g.TH * a.g.TW;
+  const int npy = (nvox * 4 + 255) / 256;
+  size_t lds = (size_t)a.g.lds_bytes + (size_t)nvox * VOXB;
+  dim3 grid(P->wg.ny * P->wg.nchunks, w.nsplit), blk(256);
+  if (npy > 4 || np > 16) return MI_ERR_BAD_ARG;
+#define MI_LAUNCH_WG(NPV)                                                                                          \
+  do {                                                                                                             \
+    auto kern = k_conv_wgrad<NPV, 4, 7>;                                                                           \
+    if (lds > 48 * 1024) {                                                                                         \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+      if (e != hipSuccess) return (int)e;                                                                          \
+    }                                                                                                              \
+    hipLaunchKernelGGL(kern, grid, blk, lds, st, w);                                                               \
+  } while (0)
+  if (np <= 4) MI_LAUNCH_WG(4);
+  else if (np <= 6) MI_LAUNCH_WG(6);
+  else if (np <= 10) MI_LAUNCH_WG(10);
+  else MI_LAUNCH_WG(16);
+#undef MI_LAUNCH_WG
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((int)(((int64_t)P->wg_nitems * 1024 + 255) / 256)), dim3(256), 0, st, P->d_part, P->wg_split_stride,
+                     P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

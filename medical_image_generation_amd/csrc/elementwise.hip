@@ -1,0 +1,358 @@
+// Memory-bound helpers of the train step: layout changes at the model boundary, nearest up-sampling,
+// space<->depth rearrangements (strided convs), channel-range copies (skip concat), q-sample, MSE,
+// timestep embedding, column sums.  All HBM-bound: 16-byte accesses, grid-stride, no LDS except reductions.
+#include "common.h"
+#include "medimgen_hip.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+inline int grid_for(int64_t work, int cap = 256 * 16) {
+  int64_t g = (work + kThreads - 1) / kThreads;
+  if (g < 1) g = 1;
+  return (int)(g > cap ? cap : g);
+}
+
+// ---------------------------------------------------------------- NCDHW fp32 <-> NDHWC bf16
+__global__ void k_ncdhw_to_ndhwc(const float* __restrict__ src, bf16* __restrict__ dst, int C, int64_t V, int64_t total) {
+  // one thread per (n, v): strided-by-V reads are coalesced across the wave, writes are 2C contiguous bytes
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t n = i / V, v = i - n * V;
+    const float* s = src + n * C * V + v;
+    bf16* d = dst + i * C;
+    for (int c = 0; c < C; ++c) d[c] = f2bf(s[(int64_t)c * V]);
+  }
+}
+__global__ void k_ndhwc_to_ncdhw(const bf16* __restrict__ src, float* __restrict__ dst, int C, int64_t V, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t n = i / V, v = i - n * V;
+    const bf16* s = src + i * C;
+    float* d = dst + n * C * V + v;
+    for (int c = 0; c < C; ++c) d[(int64_t)c * V] = bf2f(s[c]);
+  }
+}
+
+// ---------------------------------------------------------------- flat elementwise (8 bf16 per thread-step)
+__global__ void k_add_bf16(const u32x4* __restrict__ a, const u32x4* __restrict__ b, u32x4* __restrict__ o, int64_t n8) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    F8 x = unpack8(a[i]), y = unpack8(b[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x.v[j] += y.v[j];
+    o[i] = pack8(x);
+  }
+}
+__global__ void k_add_bf16_tail(const bf16* a, const bf16* b, bf16* o, int64_t start, int64_t n) {
+  int64_t i = start + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) o[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+__global__ void k_cast_f32_bf16(const float* __restrict__ s, bf16* __restrict__ d, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = f2bf(s[i]);
+}
+__global__ void k_cast_bf16_f32(const bf16* __restrict__ s, float* __restrict__ d, int64_t n, int accumulate) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = accumulate ? d[i] + bf2f(s[i]) : bf2f(s[i]);
+}
+
+// ---------------------------------------------------------------- channel-range copy (concat / split)
+// dst[v][c0d + c] = src[v][c0s + c], c in [0, nC); nC, Cs, Cd, c0s, c0d all multiples of 8
+__global__ void k_copy_channels(const bf16* __restrict__ src, int Cs, int c0s, bf16* __restrict__ dst, int Cd, int c0d,
+                                int nC8, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t v = i / nC8;
+    int c = (int)(i - v * nC8) * 8;
+    *(u32x4*)(dst + v * Cd + c0d + c) = *(const u32x4*)(src + v * Cs + c0s + c);
+  }
+}
+
+// ---------------------------------------------------------------- nearest up-sampling (integer factors per axis)
+// fwd: y[n, d, h, w, :] = x[n, d/fd, h/fh, w/fw, :]
+__global__ void k_upsample_fwd(const bf16* __restrict__ x, bf16* __restrict__ y, int D, int H, int W, int C8, int fd, int fh,
+                               int fw, int64_t total) {
+  int Do = D * fd, Ho = H * fh, Wo = W * fw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C8);
+    int64_t t = i / C8;
+    int w = (int)(t % Wo); t /= Wo;
+    int h = (int)(t % Ho); t /= Ho;
+    int d = (int)(t % Do);
+    int64_t n = t / Do;
+    int64_t src = (((n * D + d / fd) * H + h / fh) * W + w / fw) * C8 + c;
+    ((u32x4*)y)[i] = ((const u32x4*)x)[src];
+  }
+}
+// bwd: dx[n, d, h, w, :] = sum over the fd*fh*fw replicas (fp32 accumulate)
+__global__ void k_upsample_bwd(const bf16* __restrict__ dy, bf16* __restrict__ dx, int D, int H, int W, int C8, int fd, int fh,
+                               int fw, int64_t total) {
+  int Ho = H * fh, Wo = W * fw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C8);
+    int64_t t = i / C8;
+    int w = (int)(t % W); t /= W;
+    int h = (int)(t % H); t /= H;
+    int d = (int)(t % D);
+    int64_t n = t / D;
+    F8 acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+    for (int a = 0; a < fd; ++a)
+      for (int b = 0; b < fh; ++b)
+        for (int e = 0; e < fw; ++e) {
+          int64_t src = (((n * D * fd + d * fd + a) * Ho + h * fh + b) * Wo + w * fw + e) * C8 + c;
+          F8 g = unpack8(((const u32x4*)dy)[src]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc.v[j] += g.v[j];
+        }
+    ((u32x4*)dx)[i] = pack8(acc);
+  }
+}
+
+// ---------------------------------------------------------------- space <-> depth (per-axis factor 1 or 2)
+// s2d: out[n, d', h', w', q*C + c] = in[n, d'*fd + qd, h'*fh + qh, w'*fw + qw, c], q = (qd*fh + qh)*fw + qw
+// (positions beyond the input extent read as zero: odd sizes).  d2s is the inverse scatter.
+__global__ void k_space_depth(const bf16* __restrict__ in, bf16* __restrict__ out, int D, int H, int W, int C8, int fd, int fh,
+                              int fw, int Dp, int Hp, int Wp, int to_depth, int64_t total) {
+  int Q = fd * fh * fw;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    // i enumerates the DEPTH-side tensor: [n, Dp, Hp, Wp, Q, C8]
+    int c = (int)(i % C8);
+    int64_t t = i / C8;
+    int q = (int)(t % Q); t /= Q;
+    int w = (int)(t % Wp); t /= Wp;
+    int h = (int)(t % Hp); t /= Hp;
+    int d = (int)(t % Dp);
+    int64_t n = t / Dp;
+    int qw = q % fw, qh = (q / fw) % fh, qd = q / (fw * fh);
+    int sd = d * fd + qd, sh = h * fh + qh, sw = w * fw + qw;
+    bool inside = sd < D && sh < H && sw < W;
+    int64_t sp = (((n * D + sd) * H + sh) * W + sw) * C8 + c;
+    if (to_depth) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      ((u32x4*)out)[i] = inside ? ((const u32x4*)in)[sp] : z;
+    } else if (inside) {
+      ((u32x4*)out)[sp] = ((const u32x4*)in)[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------- q-sample and MSE at the model boundary
+// x_t = a[n] * x0 + b[n] * noise, NCDHW fp32 in, NDHWC bf16 out (T-LDM:160; closed form oracle/step.py)
+__global__ void k_qsample(const float* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ sqrt_acp,
+                          const float* __restrict__ sqrt_1macp, const int64_t* __restrict__ t, bf16* __restrict__ out, int C,
+                          int64_t V, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t n = i / V, v = i - n * V;
+    float a = sqrt_acp[t[n]], b = sqrt_1macp[t[n]];
+    for (int c = 0; c < C; ++c) {
+      int64_t s = (n * C + c) * V + v;
+      out[i * C + c] = f2bf(a * x0[s] + b * noise[s]);
+    }
+  }
+}
+// loss = mean((pred - target)^2) over all elements; dpred = 2 (pred - target) / numel * loss_scale.
+// pred NDHWC bf16, target NCDHW fp32, dpred NDHWC bf16.  loss accumulated with one atomic per block into *loss_sum.
+__global__ void k_mse(const bf16* __restrict__ pred, const float* __restrict__ target, bf16* __restrict__ dpred,
+                      float* __restrict__ loss_sum, int C, int64_t V, int64_t total, float inv_numel) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t n = i / V, v = i - n * V;
+    for (int c = 0; c < C; ++c) {
+      float d = bf2f(pred[i * C + c]) - target[(n * C + c) * V + v];
+      acc += d * d;
+      if (dpred) dpred[i * C + c] = f2bf(2.f * d * inv_numel);
+    }
+  }
+  float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, s * inv_numel);
+}
+
+// ---------------------------------------------------------------- sinusoidal timestep embedding (UNet:461-485)
+__global__ void k_timestep_embedding(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim, float neg_log_period) {
+  int half = dim / 2;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * dim) return;
+  int b = i / dim, j = i - b * dim;
+  float v = 0.f;
+  if (j < 2 * half) {
+    int k = j < half ? j : j - half;
+    // freq rounded once from fp64 (== torch's CPU fp32 exp to within an ulp); at t ~ 1000 an ulp of freq is 1e-4 rad
+    float freq = (float)exp((double)(neg_log_period * (float)k) / (double)half);
+    float arg = (float)t[b] * freq;
+    v = j < half ? cosf(arg) : sinf(arg);
+  }
+  out[i] = v;  // odd dim: last column zero-padded
+}
+
+// small fp32 vectors (time embedding MLP): y = silu(x) / dx = dy * silu'(x)
+__global__ void k_silu_f32(const float* x, float* y, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) y[i] = silu_f(x[i]);
+}
+__global__ void k_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n) {
+  int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = dy[i] * silu_grad_f(x[i]);
+}
+
+// ---------------------------------------------------------------- column sums: out[n][c] (+)= sum_v x[n][v][c]
+// grid (chunks, N); one block reduces a V-range for all C channels; partial results are added with fp32 atomics
+// (C floats per block -> a few thousand atomics per call, far below the atomic rate).
+__global__ void k_colsum(const bf16* __restrict__ x, float* __restrict__ out, int C, int64_t V, int64_t vchunk) {
+  extern __shared__ float sm[];  // [rows][C]
+  int n = blockIdx.y;
+  int C8 = C / 8;
+  int rows = blockDim.x / C8;  // voxel lanes
+  int cg = threadIdx.x % C8, r = threadIdx.x / C8;
+  int64_t v0 = blockIdx.x * vchunk, v1 = v0 + vchunk < V ? v0 + vchunk : V;
+  F8 acc;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+  if (r < rows)
+    for (int64_t v = v0 + r; v < v1; v += rows) {
+      F8 g = unpack8(*(const u32x4*)(x + ((int64_t)n * V + v) * C + cg * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc.v[j] += g.v[j];
+    }
+  if (r < rows)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sm[r * C + cg * 8 + j] = acc.v[j];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < rows; ++k) s += sm[k * C + c];
+    atomicAdd(out + (int64_t)n * C + c, s);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi_ncdhw_f32_to_ndhwc_bf16(const float* src, void* dst, int N, int C, int64_t V, hipStream_t st) {
+  if (N <= 0 || C <= 0 || V <= 0) return MI_ERR_BAD_ARG;
+  int64_t total = (int64_t)N * V;
+  hipLaunchKernelGGL(k_ncdhw_to_ndhwc, dim3(grid_for(total)), dim3(kThreads), 0, st, src, (bf16*)dst, C, V, total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_ndhwc_bf16_to_ncdhw_f32(const void* src, float* dst, int N, int C, int64_t V, hipStream_t st) {
+  if (N <= 0 || C <= 0 || V <= 0) return MI_ERR_BAD_ARG;
+  int64_t total = (int64_t)N * V;
+  hipLaunchKernelGGL(k_ndhwc_to_ncdhw, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)src, dst, C, V, total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_add_bf16(const void* a, const void* b, void* out, int64_t n, hipStream_t st) {
+  if (n <= 0) return MI_ERR_BAD_ARG;
+  if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) != 0) return MI_ERR_BAD_ARG;
+  int64_t n8 = n / 8;
+  if (n8 > 0) hipLaunchKernelGGL(k_add_bf16, dim3(grid_for(n8)), dim3(kThreads), 0, st, (const u32x4*)a, (const u32x4*)b, (u32x4*)out, n8);
+  if (n8 * 8 < n)
+    hipLaunchKernelGGL(k_add_bf16_tail, dim3(1), dim3(64), 0, st, (const bf16*)a, (const bf16*)b, (bf16*)out, n8 * 8, n);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_cast_f32_to_bf16(const float* src, void* dst, int64_t n, hipStream_t st) {
+  if (n <= 0) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_cast_f32_bf16, dim3(grid_for(n)), dim3(kThreads), 0, st, src, (bf16*)dst, n);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_cast_bf16_to_f32(const void* src, float* dst, int64_t n, int accumulate, hipStream_t st) {
+  if (n <= 0) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_cast_bf16_f32, dim3(grid_for(n)), dim3(kThreads), 0, st, (const bf16*)src, dst, n, accumulate);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_copy_channels(const void* src, int Cs, int c0s, void* dst, int Cd, int c0d, int nC, int64_t nvox, hipStream_t st) {
+  if ((Cs | c0s | Cd | c0d | nC) & 7 || nC <= 0 || nvox <= 0 || c0s + nC > Cs || c0d + nC > Cd) return MI_ERR_BAD_ARG;
+  int64_t total = nvox * (nC / 8);
+  hipLaunchKernelGGL(k_copy_channels, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)src, Cs, c0s, (bf16*)dst, Cd, c0d,
+                     nC / 8, total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_upsample_nearest_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t st) {
+  if (C & 7 || fd < 1 || fh < 1 || fw < 1) return MI_ERR_BAD_ARG;
+  int64_t total = (int64_t)N * D * fd * H * fh * W * fw * (C / 8);
+  hipLaunchKernelGGL(k_upsample_fwd, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)x, (bf16*)y, D, H, W, C / 8, fd, fh, fw, total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_upsample_nearest_bwd(const void* dy, void* dx, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t st) {
+  if (C & 7 || fd < 1 || fh < 1 || fw < 1) return MI_ERR_BAD_ARG;
+  int64_t total = (int64_t)N * D * H * W * (C / 8);
+  hipLaunchKernelGGL(k_upsample_bwd, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)dy, (bf16*)dx, D, H, W, C / 8, fd, fh, fw, total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_space_to_depth(const void* in, void* out, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t st) {
+  if (C & 7) return MI_ERR_BAD_ARG;
+  int Dp = (D + fd - 1) / fd, Hp = (H + fh - 1) / fh, Wp = (W + fw - 1) / fw;
+  int64_t total = (int64_t)N * Dp * Hp * Wp * fd * fh * fw * (C / 8);
+  hipLaunchKernelGGL(k_space_depth, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)in, (bf16*)out, D, H, W, C / 8, fd, fh, fw, Dp, Hp, Wp, 1, total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_depth_to_space(const void* in, void* out, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t st) {
+  // (D, H, W, C) describe the SPACE-side tensor `out`; `in` is [N, ceil(D/fd), ceil(H/fh), ceil(W/fw), fd*fh*fw*C]
+  if (C & 7) return MI_ERR_BAD_ARG;
+  int Dp = (D + fd - 1) / fd, Hp = (H + fh - 1) / fh, Wp = (W + fw - 1) / fw;
+  int64_t total = (int64_t)N * Dp * Hp * Wp * fd * fh * fw * (C / 8);
+  hipLaunchKernelGGL(k_space_depth, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)in, (bf16*)out, D, H, W, C / 8, fd, fh, fw, Dp, Hp, Wp, 0, total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_qsample(const float* x0, const float* noise, const float* sqrt_acp, const float* sqrt_1macp, const int64_t* t, void* out,
+               int N, int C, int64_t V, hipStream_t st) {
+  int64_t total = (int64_t)N * V;
+  if (total <= 0) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_qsample, dim3(grid_for(total)), dim3(kThreads), 0, st, x0, noise, sqrt_acp, sqrt_1macp, t, (bf16*)out, C, V, total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_mse_fwd_bwd(const void* pred, const float* target, void* dpred, float* loss, int N, int C, int64_t V, float grad_scale,
+                   hipStream_t st) {
+  int64_t total = (int64_t)N * V;
+  if (total <= 0) return MI_ERR_BAD_ARG;
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  (void)grad_scale;
+  hipLaunchKernelGGL(k_mse, dim3(grid_for(total, 1024)), dim3(kThreads), 0, st, (const bf16*)pred, target, (bf16*)dpred, loss, C, V, total,
+                     1.0f / (float)(total * C));
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_timestep_embedding(const int64_t* t, float* out, int B, int dim, float max_period, hipStream_t st) {
+  if (B <= 0 || dim <= 0) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_timestep_embedding, dim3(ceil_div((int64_t)B * dim, 256)), dim3(256), 0, st, t, out, B, dim, -logf(max_period));
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_silu_f32(const float* x, float* y, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_silu_f32, dim3(ceil_div(n, 256)), dim3(256), 0, st, x, y, n);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(k_silu_bwd_f32, dim3(ceil_div(n, 256)), dim3(256), 0, st, x, dy, dx, n);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_colsum_bf16(const void* x, float* out, int N, int64_t V, int C, int accumulate, hipStream_t st) {
+  if (C & 7 || C > 2048 || N <= 0 || V <= 0) return MI_ERR_BAD_ARG;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N * C, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  int C8 = C / 8;
+  int threads = 256;
+  if (C8 > threads) threads = ((C8 + 63) / 64) * 64;
+  int rows = threads / C8;
+  int64_t vchunk = 2048;
+  int chunks = ceil_div(V, vchunk);
+  hipLaunchKernelGGL(k_colsum, dim3(chunks, N), dim3(threads), sizeof(float) * (size_t)rows * C, st, (const bf16*)x, out, C, V, vchunk);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,300 @@
+// GroupNorm (+SiLU) statistics / apply / backward on NDHWC bf16 activations (UNet:628,648,377,1932; AEKL:157,167,451,604).
+//
+// HBM-bound.  Statistics are two-level: per-(n, V-chunk, channel) fp32 partial sums written to a workspace by a
+// streaming kernel (16-byte loads, 8 channels per lane, LDS reduction over the voxel lanes of the block), then one
+// small block per (n, group) finishes in fp64 and emits the per-(n, channel) affine pair
+//     scale = gamma * rstd,   shift = beta - mean * scale
+// that conv prologues / the apply kernel consume, so "normalise" is a single FMA per element downstream.
+// Backward uses the same two-level shape: partial sums of du and du*x, a per-(n, group) finish producing the three
+// coefficients of  dx = a*du + b*x + c  per (n, channel), and a streaming apply.
+#include "common.h"
+#include "medimgen_hip.h"
+
+namespace {
+
+constexpr int kT = 256;
+
+struct Geo {
+  int C8;    // channel groups of 8
+  int rows;  // voxel lanes per block = kT / C8
+};
+
+__device__ __forceinline__ void load_ss(const float* ss, int c0, float* sc, float* sh) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sc[j] = ss[2 * (c0 + j)];
+    sh[j] = ss[2 * (c0 + j) + 1];
+  }
+}
+
+// partial[n][chunk][c][2] = (sum x, sum x^2) over the chunk's voxels
+__global__ void __launch_bounds__(kT) k_gn_partial(const bf16* __restrict__ x, int cstride, float* __restrict__ partial, int C,
+                                                   int64_t V, int64_t vchunk) {
+  extern __shared__ float sm[];  // [rows][C][2]
+  const int C8 = C / 8, rows = kT / C8;
+  const int cg = threadIdx.x % C8, r = threadIdx.x / C8;
+  const int n = blockIdx.y;
+  const int64_t v0 = blockIdx.x * vchunk, v1 = (v0 + vchunk < V) ? v0 + vchunk : V;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  if (r < rows)
+    for (int64_t v = v0 + r; v < v1; v += rows) {
+      F8 f = unpack8(*(const u32x4*)(x + ((int64_t)n * V + v) * cstride + cg * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        s[j] += f.v[j];
+        q[j] += f.v[j] * f.v[j];
+      }
+    }
+  if (r < rows)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sm[(r * C + cg * 8 + j) * 2] = s[j];
+      sm[(r * C + cg * 8 + j) * 2 + 1] = q[j];
+    }
+  __syncthreads();
+  float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * C * 2;
+  for (int i = threadIdx.x; i < 2 * C; i += kT) {
+    float a = 0.f;
+    for (int k = 0; k < rows; ++k) a += sm[k * C * 2 + i];
+    out[i] = a;
+  }
+}
+
+// one block (64 threads) per (n, g)
+__global__ void k_gn_finalize(const float* __restrict__ partial, int chunks, int C, int G, int64_t V, float eps,
+                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale_shift,
+                              float* __restrict__ mean_rstd) {
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  double s = 0.0, q = 0.0;
+  for (int i = threadIdx.x; i < chunks * cpg; i += 64) {
+    int ch = i / cpg, c = g * cpg + i % cpg;
+    const float* p = partial + (((int64_t)n * chunks + ch) * C + c) * 2;
+    s += (double)p[0];
+    q += (double)p[1];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    q += __shfl_xor(q, off, 64);
+  }
+  const double m = (double)V * cpg;
+  const double mean = s / m;
+  double var = q / m - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    mean_rstd[((int64_t)n * G + g) * 2] = (float)mean;
+    mean_rstd[((int64_t)n * G + g) * 2 + 1] = rstd;
+  }
+  for (int i = threadIdx.x; i < cpg; i += 64) {
+    int c = g * cpg + i;
+    float sc = gamma[c] * rstd;
+    scale_shift[((int64_t)n * C + c) * 2] = sc;
+    scale_shift[((int64_t)n * C + c) * 2 + 1] = beta[c] - (float)mean * sc;
+  }
+}
+
+// y = act(x * scale + shift)
+__global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int xcs, const float* __restrict__ scale_shift,
+                                                 bf16* __restrict__ y, int ycs, int C8, int64_t V, int silu, int64_t total) {
+  const int C = C8 * 8;
+  for (int64_t i = blockIdx.x * (int64_t)kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    int cg = (int)(i % C8);
+    int64_t nv = i / C8;
+    int64_t n = nv / V;
+    float sc[8], sh[8];
+    load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
+    F8 f = unpack8(*(const u32x4*)(x + nv * xcs + cg * 8));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float u = f.v[j] * sc[j] + sh[j];
+      f.v[j] = silu ? silu_f(u) : u;
+    }
+    *(u32x4*)(y + nv * ycs + cg * 8) = pack8(f);
+  }
+}
+
+// backward partials: (sum du, sum du*x) per (n, chunk, c);  du = g * silu'(x*scale+shift)  (or g when !silu)
+__global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
+                                                       const float* __restrict__ scale_shift, float* __restrict__ partial, int C,
+                                                       int64_t V, int64_t vchunk, int silu) {
+  extern __shared__ float sm[];
+  const int C8 = C / 8, rows = kT / C8;
+  const int cg = threadIdx.x % C8, r = threadIdx.x / C8;
+  const int n = blockIdx.y;
+  const int64_t v0 = blockIdx.x * vchunk, v1 = (v0 + vchunk < V) ? v0 + vchunk : V;
+  float s1[8], s2[8], sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+  if (r < rows) {
+    load_ss(scale_shift + (int64_t)n * C * 2, cg * 8, sc, sh);
+    for (int64_t v = v0 + r; v < v1; v += rows) {
+      F8 fx = unpack8(*(const u32x4*)(x + ((int64_t)n * V + v) * xcs + cg * 8));
+      F8 fg = unpack8(*(const u32x4*)(g + ((int64_t)n * V + v) * gcs + cg * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float du = fg.v[j];
+        if (silu) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
+        s1[j] += du;
+        s2[j] += du * fx.v[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      sm[(r * C + cg * 8 + j) * 2] = s1[j];
+      sm[(r * C + cg * 8 + j) * 2 + 1] = s2[j];
+    }
+  }
+  __syncthreads();
+  float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * C * 2;
+  for (int i = threadIdx.x; i < 2 * C; i += kT) {
+    float a = 0.f;
+    for (int k = 0; k < rows; ++k) a += sm[k * C * 2 + i];
+    out[i] = a;
+  }
+}
+
+// per (n, g): coefficients of dx = a*du + b*x + c per channel, and the affine-parameter gradients
+__global__ void k_gn_bwd_finalize(const float* __restrict__ partial, int chunks, int C, int G, int64_t V,
+                                  const float* __restrict__ gamma, const float* __restrict__ mean_rstd, float* __restrict__ coef,
+                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ float sm[];  // [cpg][2] channel sums
+  const int n = blockIdx.x / G, g = blockIdx.x % G;
+  const int cpg = C / G;
+  const float mean = mean_rstd[((int64_t)n * G + g) * 2], rstd = mean_rstd[((int64_t)n * G + g) * 2 + 1];
+  double m1 = 0.0, m2 = 0.0;
+  for (int i = threadIdx.x; i < cpg; i += 64) {
+    int c = g * cpg + i;
+    double s1 = 0.0, s2 = 0.0;
+    for (int ch = 0; ch < chunks; ++ch) {
+      const float* p = partial + (((int64_t)n * chunks + ch) * C + c) * 2;
+      s1 += (double)p[0];
+      s2 += (double)p[1];
+    }
+    double s2hat = (double)rstd * (s2 - (double)mean * s1);  // sum du * xhat
+    sm[2 * i] = (float)s1;
+    sm[2 * i + 1] = (float)s2hat;
+    m1 += (double)gamma[c] * s1;
+    m2 += (double)gamma[c] * s2hat;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    m1 += __shfl_xor(m1, off, 64);
+    m2 += __shfl_xor(m2, off, 64);
+  }
+  const double m = (double)V * cpg;
+  m1 /= m;
+  m2 /= m;
+  const float b = (float)(-(double)rstd * rstd * m2);
+  const float c0 = (float)((double)rstd * rstd * m2 * mean - (double)rstd * m1);
+  for (int i = threadIdx.x; i < cpg; i += 64) {
+    int c = g * cpg + i;
+    float* o = coef + ((int64_t)n * C + c) * 3;
+    o[0] = rstd * gamma[c];
+    o[1] = b;
+    o[2] = c0;
+    if (dbeta) atomicAdd(dbeta + c, sm[2 * i]);
+    if (dgamma) atomicAdd(dgamma + c, sm[2 * i + 1]);
+  }
+}
+
+// dx = a*du + b*x + c (+ add)
+__global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
+                                                     const float* __restrict__ scale_shift, const float* __restrict__ coef,
+                                                     const bf16* __restrict__ add, int acs, bf16* __restrict__ dx, int dcs, int C8,
+                                                     int64_t V, int silu, int64_t total) {
+  const int C = C8 * 8;
+  for (int64_t i = blockIdx.x * (int64_t)kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
+    int cg = (int)(i % C8);
+    int64_t nv = i / C8;
+    int64_t n = nv / V;
+    float sc[8], sh[8];
+    load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
+    const float* cf = coef + (n * C + cg * 8) * 3;
+    F8 fx = unpack8(*(const u32x4*)(x + nv * xcs + cg * 8));
+    F8 fg = unpack8(*(const u32x4*)(g + nv * gcs + cg * 8));
+    F8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float du = fg.v[j];
+      if (silu) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
+      o.v[j] = cf[3 * j] * du + cf[3 * j + 1] * fx.v[j] + cf[3 * j + 2];
+    }
+    if (add) {
+      F8 fa = unpack8(*(const u32x4*)(add + nv * acs + cg * 8));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o.v[j] += fa.v[j];
+    }
+    *(u32x4*)(dx + nv * dcs + cg * 8) = pack8(o);
+  }
+}
+
+inline int64_t pick_vchunk(int64_t V) {
+  int64_t vc = 2048;
+  while ((V + vc - 1) / vc > 1024) vc *= 2;
+  return vc;
+}
+inline bool bad_c(int C, int G) { return C <= 0 || (C & 7) || C > 2048 || G <= 0 || C % G != 0; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t mi_gn_workspace_bytes(int N, int64_t V, int C) {
+  int64_t vc = pick_vchunk(V);
+  return (int64_t)N * ((V + vc - 1) / vc) * C * 2 * (int64_t)sizeof(float);
+}
+
+int mi_gn_stats(const void* x, int x_cstride, int N, int64_t V, int C, int G, float eps, const float* gamma, const float* beta,
+                float* scale_shift, float* mean_rstd, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  if (bad_c(C, G) || N <= 0 || V <= 0 || (x_cstride & 7) || x_cstride < C) return MI_ERR_BAD_ARG;
+  if (workspace_bytes < mi_gn_workspace_bytes(N, V, C)) return MI_ERR_BAD_ARG;
+  int64_t vc = pick_vchunk(V);
+  int chunks = (int)((V + vc - 1) / vc);
+  int rows = kT / (C / 8);
+  hipLaunchKernelGGL(k_gn_partial, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)x, x_cstride,
+                     (float*)workspace, C, V, vc);
+  hipLaunchKernelGGL(k_gn_finalize, dim3(N * G), dim3(64), 0, st, (const float*)workspace, chunks, C, G, V, eps, gamma, beta,
+                     scale_shift, mean_rstd);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y, int y_cstride, int N, int64_t V, int C, int silu,
+                hipStream_t st) {
+  if (C <= 0 || (C & 7) || (x_cstride & 7) || (y_cstride & 7) || N <= 0 || V <= 0) return MI_ERR_BAD_ARG;
+  int64_t total = (int64_t)N * V * (C / 8);
+  int64_t grid = (total + kT - 1) / kT;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(k_gn_apply, dim3((int)grid), dim3(kT), 0, st, (const bf16*)x, x_cstride, scale_shift, (bf16*)y, y_cstride, C / 8, V,
+                     silu, total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N, int64_t V, int C, int G, const float* gamma,
+              const float* scale_shift, const float* mean_rstd, int silu, const void* add, int add_cstride, void* dx, int dx_cstride,
+              float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  if (bad_c(C, G) || N <= 0 || V <= 0 || (x_cstride & 7) || (g_cstride & 7) || (dx_cstride & 7) || (add && (add_cstride & 7)))
+    return MI_ERR_BAD_ARG;
+  if (workspace_bytes < mi_gn_workspace_bytes(N, V, C)) return MI_ERR_BAD_ARG;
+  int64_t vc = pick_vchunk(V);
+  int chunks = (int)((V + vc - 1) / vc);
+  int rows = kT / (C / 8);
+  hipLaunchKernelGGL(k_gn_bwd_partial, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride,
+                     (const bf16*)x, x_cstride, scale_shift, (float*)workspace, C, V, vc, silu);
+  hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(N * G), dim3(64), sizeof(float) * 2 * (size_t)(C / G), st, (const float*)workspace, chunks, C,
+                     G, V, gamma, mean_rstd, coef, dgamma, dbeta);
+  int64_t total = (int64_t)N * V * (C / 8);
+  int64_t grid = (total + kT - 1) / kT;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(k_gn_bwd_apply, dim3((int)grid), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift,
+                     coef, (const bf16*)add, add_cstride, (bf16*)dx, dx_cstride, C / 8, V, silu, total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // extern "C"

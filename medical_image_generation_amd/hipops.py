@@ -1,0 +1,275 @@
+"""Raw (non-autograd) wrappers over the C ABI: one Python function per kernel family.
+
+Tensors: activations are channels-last bf16 `[N, D, H, W, C]` (2-D nets use D = 1), fp32
+for weights / statistics / gradients.  Outputs are allocated with torch.empty (caching
+allocator, hipGraph-friendly); nothing here computes with torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _vox(t):  # [N, D, H, W, C] -> (N, V, C)
+    n, d, h, w, c = t.shape
+    return n, d * h * w, c
+
+
+def _cs(t):
+    """channel stride (elements per voxel) of a channels-last activation (may be a channel slice of a wider buffer)."""
+    assert t.dim() == 5
+    if t.is_contiguous():  # also covers size-1 dims, whose strides torch does not normalise
+        return t.shape[-1]
+    assert t.stride(-1) == 1
+    cs = t.stride(3)
+    assert t.stride(2) == t.shape[3] * cs and t.stride(1) == t.shape[2] * t.stride(2) and t.stride(0) == t.shape[1] * t.stride(1), \
+        "activation must be dense in N, D, H, W"
+    return cs
+
+
+# ----------------------------------------------------------------------------- layout
+def to_channels_last(x_ncdhw: torch.Tensor) -> torch.Tensor:
+    """fp32 NCDHW (or NCHW) -> bf16 NDHWC."""
+    x = x_ncdhw.contiguous()
+    if x.dim() == 4:
+        x = x.unsqueeze(2)
+    n, c, d, h, w = x.shape
+    out = torch.empty((n, d, h, w, c), dtype=BF16, device=x.device)
+    call("mi_ncdhw_f32_to_ndhwc_bf16", ptr(x), ptr(out), n, c, d * h * w)
+    return out
+
+
+def to_channels_first(x_cl: torch.Tensor, spatial_dims: int = 3) -> torch.Tensor:
+    """bf16 NDHWC -> fp32 NCDHW (NCHW when spatial_dims == 2)."""
+    assert x_cl.is_contiguous()
+    n, d, h, w, c = x_cl.shape
+    out = torch.empty((n, c, d, h, w), dtype=F32, device=x_cl.device)
+    call("mi_ndhwc_bf16_to_ncdhw_f32", ptr(x_cl), ptr(out), n, c, d * h * w)
+    return out.squeeze(2) if spatial_dims == 2 else out
+
+
+def add(a, b):
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    out = torch.empty_like(a)
+    call("mi_add_bf16", ptr(a), ptr(b), ptr(out), a.numel())
+    return out
+
+
+def concat_channels(a, b):
+    n, v, ca = _vox(a)
+    cb = b.shape[-1]
+    out = torch.empty(a.shape[:-1] + (ca + cb,), dtype=BF16, device=a.device)
+    call("mi_copy_channels", ptr(a), _cs(a), 0, ptr(out), ca + cb, 0, ca, n * v)
+    call("mi_copy_channels", ptr(b), _cs(b), 0, ptr(out), ca + cb, ca, cb, n * v)
+    return out
+
+
+def slice_channels(x, c0, nc):
+    n, v, c = _vox(x)
+    out = torch.empty(x.shape[:-1] + (nc,), dtype=BF16, device=x.device)
+    call("mi_copy_channels", ptr(x), _cs(x), c0, ptr(out), nc, 0, nc, n * v)
+    return out
+
+
+def upsample_nearest(x, f):
+    n, d, h, w, c = x.shape
+    out = torch.empty((n, d * f[0], h * f[1], w * f[2], c), dtype=BF16, device=x.device)
+    call("mi_upsample_nearest_fwd", ptr(x), ptr(out), n, d, h, w, c, f[0], f[1], f[2])
+    return out
+
+
+def upsample_nearest_bwd(dy, f):
+    n, d, h, w, c = dy.shape
+    out = torch.empty((n, d // f[0], h // f[1], w // f[2], c), dtype=BF16, device=dy.device)
+    call("mi_upsample_nearest_bwd", ptr(dy), ptr(out), n, d // f[0], h // f[1], w // f[2], c, f[0], f[1], f[2])
+    return out
+
+
+# ----------------------------------------------------------------------------- GroupNorm
+_ws_cache: dict = {}
+
+
+def _workspace(nbytes, device):
+    key = (device.index, "gn")
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+class GNStats:
+    __slots__ = ("scale_shift", "mean_rstd", "groups")
+
+    def __init__(self, scale_shift, mean_rstd, groups):
+        self.scale_shift, self.mean_rstd, self.groups = scale_shift, mean_rstd, groups
+
+
+def gn_stats(x, groups, eps, gamma, beta) -> GNStats:
+    n, v, c = _vox(x)
+    ss = torch.empty((n, c, 2), dtype=F32, device=x.device)
+    mr = torch.empty((n, groups, 2), dtype=F32, device=x.device)
+    nb = _lib.call_raw("mi_gn_workspace_bytes", n, v, c)
+    ws = _workspace(nb, x.device)
+    call("mi_gn_stats", ptr(x), _cs(x), n, v, c, groups, float(eps), ptr(gamma), ptr(beta), ptr(ss), ptr(mr), ptr(ws), ws.numel())
+    return GNStats(ss, mr, groups)
+
+
+def gn_apply(x, st: GNStats, silu: bool):
+    n, v, c = _vox(x)
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    call("mi_gn_apply", ptr(x), _cs(x), ptr(st.scale_shift), ptr(y), c, n, v, c, int(silu))
+    return y
+
+
+def gn_bwd(g, x, st: GNStats, gamma, silu: bool, dgamma, dbeta, add=None):
+    """g = dL/d(act(GN(x))) -> dL/dx (+ add); dgamma/dbeta (fp32) are accumulated in place."""
+    n, v, c = _vox(x)
+    dx = torch.empty(x.shape, dtype=BF16, device=x.device)
+    coef = torch.empty((n, c, 3), dtype=F32, device=x.device)
+    nb = _lib.call_raw("mi_gn_workspace_bytes", n, v, c)
+    ws = _workspace(nb, x.device)
+    call("mi_gn_bwd", ptr(g), _cs(g), ptr(x), _cs(x), n, v, c, st.groups, ptr(gamma), ptr(st.scale_shift), ptr(st.mean_rstd),
+         int(silu), ptr(add), _cs(add) if add is not None else 0, ptr(dx), c, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(ws), ws.numel())
+    return dx
+
+
+# ----------------------------------------------------------------------------- convolution
+class ConvPlan:
+    """Opaque mi_conv_plan handle for one (shape, kernel, stride, padding) instance."""
+
+    def __init__(self, n, dims, cin, cout, kernel, stride, padding):
+        self.n, self.dims, self.cin, self.cout = n, tuple(dims), cin, cout
+        self.kernel, self.stride, self.padding = tuple(kernel), tuple(stride), tuple(padding)
+        h = C.c_void_p()
+        arr = lambda v: (C.c_int * 3)(*v)
+        _lib.call_raw("mi_conv_plan_create", C.byref(h), n, dims[0], dims[1], dims[2], cin, cout, arr(kernel), arr(stride), arr(padding))
+        self.handle = h
+        od = (C.c_int * 3)()
+        _lib.call_raw("mi_conv_plan_out_dims", self.handle, od)
+        self.out_dims = tuple(od)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.call_raw("mi_conv_plan_destroy", self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def pack(self, weight_f32):
+        assert weight_f32.dtype == F32 and weight_f32.is_contiguous()
+        call("mi_conv_pack_weights", self.handle, ptr(weight_f32))
+
+    def fwd(self, x, st: GNStats | None = None, silu=False, addvec=None, res=None):
+        n, d, h, w, c = x.shape
+        assert (n, (d, h, w), c) == (self.n, self.dims, self.cin), f"plan/input mismatch {x.shape} vs {self.n, self.dims, self.cin}"
+        y = torch.empty((n,) + self.out_dims + (self.cout,), dtype=BF16, device=x.device)
+        per_n = int(addvec is not None and addvec.dim() == 2)
+        call("mi_conv_fwd", self.handle, ptr(x), _cs(x), ptr(st.scale_shift) if st is not None else None, int(silu), ptr(addvec), per_n,
+             ptr(res), _cs(res) if res is not None else 0, ptr(y), self.cout)
+        return y
+
+    def dgrad(self, dy):
+        assert dy.shape == (self.n,) + self.out_dims + (self.cout,)
+        dx = torch.empty((self.n,) + self.dims + (self.cin,), dtype=BF16, device=dy.device)
+        call("mi_conv_dgrad", self.handle, ptr(dy), _cs(dy), ptr(dx), self.cin)
+        return dx
+
+    def wgrad(self, x, dy, dweight_f32, st: GNStats | None = None, silu=False):
+        assert dweight_f32.dtype == F32 and dweight_f32.is_contiguous()
+        call("mi_conv_wgrad", self.handle, ptr(x), _cs(x), ptr(st.scale_shift) if st is not None else None, int(silu), ptr(dy), _cs(dy),
+             ptr(dweight_f32))
+
+
+def colsum(x, out=None, accumulate=False):
+    n, v, c = _vox(x)
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty((n, c), dtype=F32, device=x.device)
+    call("mi_colsum_bf16", ptr(x), ptr(out), n, v, c, int(accumulate))
+    return out
+
+
+# ----------------------------------------------------------------------------- GEMM family
+def gemm_nt(a, b, *, bias=None, res=None, alpha=1.0, out=None, out_f32=False, accumulate=False):
+    """out[z] = alpha * a[z] @ b[z]^T (+bias) (+res).  a: [Z?, M, K], b: [Z?, N, K] (last dim contiguous, arbitrary row pitch)."""
+    a3, b3 = (a if a.dim() == 3 else a.unsqueeze(0)), (b if b.dim() == 3 else b.unsqueeze(0))
+    z, m, k = a3.shape
+    n = b3.shape[1]
+    assert b3.shape[2] == k and a3.stride(2) == 1 and b3.stride(2) == 1
+    zb = b3.shape[0]
+    assert zb in (1, z)
+    if out is None:
+        out = torch.empty((z, m, n), dtype=F32 if out_f32 else BF16, device=a.device)
+        out_v = out
+    else:
+        out_v = out if out.dim() == 3 else out.unsqueeze(0)
+    r3 = None
+    if res is not None:
+        r3 = res if res.dim() == 3 else res.unsqueeze(0)
+        assert r3.stride(2) == 1
+    call("mi_gemm_nt_bf16", ptr(a3), a3.stride(1), a3.stride(0), 0, ptr(b3), b3.stride(1), b3.stride(0) if zb == z else 0, 0,
+         ptr(out_v), out_v.stride(1), out_v.stride(0), 0, ptr(bias), ptr(r3), r3.stride(1) if r3 is not None else 0,
+         r3.stride(0) if r3 is not None else 0, 0, m, n, k, z, 1, float(alpha), int(out_v.dtype == F32), int(accumulate))
+    return out if a.dim() == 3 or out.dim() == 2 else out[0]
+
+
+def transpose(x):
+    """[Z?, R, C] bf16 (last dim contiguous) -> [Z?, C, R] contiguous."""
+    x3 = x if x.dim() == 3 else x.unsqueeze(0)
+    z, r, c = x3.shape
+    out = torch.empty((z, c, r), dtype=BF16, device=x.device)
+    call("mi_transpose_bf16", ptr(x3), x3.stride(1), x3.stride(0), 0, ptr(out), r, c * r, 0, r, c, z, 1)
+    return out if x.dim() == 3 else out[0]
+
+
+def softmax_fwd(scores_f32):
+    s = scores_f32.contiguous()
+    out = torch.empty(s.shape, dtype=BF16, device=s.device)
+    call("mi_softmax_fwd", ptr(s), ptr(out), s.numel() // s.shape[-1], s.shape[-1])
+    return out
+
+
+def softmax_bwd(probs, dprobs_f32, scale):
+    out = torch.empty(probs.shape, dtype=BF16, device=probs.device)
+    call("mi_softmax_bwd", ptr(probs), ptr(dprobs_f32), ptr(out), probs.numel() // probs.shape[-1], probs.shape[-1], float(scale))
+    return out
+
+
+# ----------------------------------------------------------------------------- small ops
+def timestep_embedding(t_i64, dim, max_period=10000.0):
+    out = torch.empty((t_i64.shape[0], dim), dtype=F32, device=t_i64.device)
+    call("mi_timestep_embedding", ptr(t_i64), ptr(out), t_i64.shape[0], dim, float(max_period))
+    return out
+
+
+def silu_f32(x):
+    y = torch.empty_like(x)
+    call("mi_silu_f32", ptr(x), ptr(y), x.numel())
+    return y
+
+
+def silu_bwd_f32(x, dy):
+    dx = torch.empty_like(x)
+    call("mi_silu_bwd_f32", ptr(x), ptr(dy), ptr(dx), x.numel())
+    return dx
+
+
+def cast_bf16(x_f32):
+    out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
+    call("mi_cast_f32_to_bf16", ptr(x_f32.contiguous()), ptr(out), x_f32.numel())
+    return out
+
+
+def cast_f32(x_bf16, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty(x_bf16.shape, dtype=F32, device=x_bf16.device)
+    call("mi_cast_bf16_to_f32", ptr(x_bf16), ptr(out), x_bf16.numel(), int(accumulate))
+    return out

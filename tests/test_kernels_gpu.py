@@ -1,0 +1,241 @@
+"""Kernel-level parity: every HIP kernel family, through the C ABI, against a plain PyTorch fp32 reference of the
+same op on the same bf16-rounded inputs.  Tolerance: one bf16 rounding of the output (2^-8 relative) plus
+accumulation-order noise -> |err| <= 1e-2 * max|ref| unless stated otherwise."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+dev = torch.device("cuda")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from medical_image_generation_amd import hipops
+    return hipops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).bfloat16().float()  # bf16-representable fp32
+
+
+def cl(x):  # NCDHW fp32 (cpu) -> NDHWC bf16 (gpu), via torch (test-side only)
+    return x.permute(0, 2, 3, 4, 1).contiguous().to(dev, torch.bfloat16)
+
+
+def cf(y):  # NDHWC bf16 (gpu) -> NCDHW fp32 (cpu)
+    return y.float().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def check(got, ref, tol=1e-2, what=""):
+    scale = float(ref.abs().max()) + 1e-12
+    err = float((got - ref).abs().max())
+    assert math.isfinite(err) and err <= tol * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+
+
+def test_layout_roundtrip(ops):
+    for shape in [(2, 1, 5, 6, 7), (1, 8, 4, 4, 4), (2, 32, 3, 5, 9)]:
+        x = rnd(*shape)
+        y = ops.to_channels_last(x.to(dev))
+        assert torch.equal(y.cpu(), x.permute(0, 2, 3, 4, 1).bfloat16())
+        assert torch.equal(ops.to_channels_first(y).cpu(), x)
+    x2 = rnd(2, 3, 8, 8)
+    assert torch.equal(ops.to_channels_first(ops.to_channels_last(x2.to(dev)), 2).cpu(), x2)
+
+
+def test_elementwise_family(ops):
+    a, b = rnd(2, 16, 4, 5, 6), rnd(2, 16, 4, 5, 6, seed=1)
+    check(cf(ops.add(cl(a), cl(b))), (a + b).bfloat16().float(), 1e-6, "add")
+    c = rnd(2, 24, 4, 5, 6, seed=2)
+    cat = ops.concat_channels(cl(a), cl(c))
+    assert torch.equal(cf(cat), torch.cat([a, c], 1))
+    assert torch.equal(cf(ops.slice_channels(cat, 16, 24)), c)
+    for f in [(2, 2, 2), (2, 2, 1), (1, 2, 2)]:
+        up = ops.upsample_nearest(cl(a), f)
+        ref = F.interpolate(a, scale_factor=tuple(float(v) for v in f), mode="nearest")
+        assert torch.equal(cf(up), ref)
+        g = rnd(*ref.shape, seed=3)
+        av = a.clone().requires_grad_(True)
+        F.interpolate(av, scale_factor=tuple(float(v) for v in f), mode="nearest").backward(g)
+        check(cf(ops.upsample_nearest_bwd(cl(g), f)), av.grad, 1e-2, "upsample bwd")
+    t = torch.tensor([0, 1, 17, 999], device=dev)
+    for dim in (8, 7, 32, 128):
+        from oracle.nets import timestep_embedding
+        check(ops.timestep_embedding(t, dim).cpu(), timestep_embedding(t.cpu(), dim), 5e-5, f"timestep embedding {dim}")
+    v = rnd(3, 40)
+    check(ops.silu_f32(v.to(dev)).cpu(), F.silu(v), 1e-5, "silu")
+    vv = v.clone().requires_grad_(True)
+    F.silu(vv).backward(torch.ones_like(v) * 0.5)
+    vd, hd = v.to(dev), torch.full_like(v, 0.5).to(dev)
+    check(ops.silu_bwd_f32(vd, hd).cpu(), vv.grad, 1e-5, "silu bwd")
+    x = rnd(2, 64, 3, 7, 5)
+    check(ops.colsum(cl(x)).cpu(), x.sum(dim=(2, 3, 4)), 1e-3, "colsum")
+
+
+@pytest.mark.parametrize("shape,groups", [((2, 32, 4, 6, 5), 32), ((1, 96, 8, 8, 8), 32), ((2, 64, 1, 16, 16), 16),
+                                          ((1, 16, 5, 5, 5), 8), ((1, 512, 4, 4, 4), 32)])
+@pytest.mark.parametrize("silu", [True, False])
+def test_groupnorm_fwd_bwd(ops, shape, groups, silu):
+    x = rnd(*shape, scale=1.5) + 0.3
+    x = x.bfloat16().float()
+    c = shape[1]
+    gamma, beta = 1 + 0.2 * rnd(c, seed=5), 0.1 * rnd(c, seed=6)
+    eps = 1e-6
+    xr = x.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = F.group_norm(xr, groups, gr, br, eps)
+    if silu:
+        y = F.silu(y)
+    g = rnd(*shape, seed=7)
+    y.backward(g)
+    xc = cl(x)
+    st = ops.gn_stats(xc, groups, eps, gamma.to(dev), beta.to(dev))
+    check(cf(ops.gn_apply(xc, st, silu)), y.detach(), 1e-2, "gn fwd")
+    dgamma, dbeta = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    other = rnd(*shape, seed=8)
+    dx = ops.gn_bwd(cl(g), xc, st, gamma.to(dev), silu, dgamma, dbeta, add=cl(other))
+    check(cf(dx), xr.grad + other, 1.5e-2, "gn dx")
+    check(dgamma.cpu(), gr.grad, 1e-2, "gn dgamma")
+    check(dbeta.cpu(), br.grad, 1e-2, "gn dbeta")
+
+
+@pytest.mark.parametrize("m,n,k,z", [(128, 128, 64, 1), (300, 200, 96, 2), (5, 512, 128, 1), (4096, 64, 4096, 2), (64, 70, 8, 3)])
+def test_gemm_nt(ops, m, n, k, z):
+    a, b = rnd(z, m, k), rnd(z, n, k, seed=1)
+    bias, res = rnd(n, seed=2), rnd(z, m, n, seed=3)
+    ref = 0.5 * a @ b.transpose(1, 2) + bias + res
+    out = ops.gemm_nt(a.to(dev, torch.bfloat16), b.to(dev, torch.bfloat16), bias=bias.to(dev), res=res.to(dev, torch.bfloat16), alpha=0.5)
+    check(out.float().cpu(), ref, 1e-2, "gemm bf16 out")
+    acc = torch.ones(z, m, n, device=dev)
+    ops.gemm_nt(a.to(dev, torch.bfloat16), b.to(dev, torch.bfloat16), out=acc, accumulate=True)
+    check(acc.cpu(), 1 + a @ b.transpose(1, 2), 2e-3, "gemm f32 accumulate")
+    # strided operands: column slices of a wider matrix (how q/k/v heads are addressed)
+    wide = rnd(z, m, 3 * k, seed=4).to(dev, torch.bfloat16)
+    out2 = ops.gemm_nt(wide[:, :, k:2 * k], b.to(dev, torch.bfloat16), out_f32=True)
+    check(out2.cpu(), wide[:, :, k:2 * k].float().cpu() @ b.transpose(1, 2), 2e-3, "gemm strided A")
+
+
+def test_transpose_softmax(ops):
+    x = rnd(3, 70, 130).to(dev, torch.bfloat16)
+    assert torch.equal(ops.transpose(x), x.transpose(1, 2).contiguous())
+    s = rnd(2, 50, 777, scale=3.0)
+    p = ops.softmax_fwd(s.to(dev))
+    check(p.float().cpu(), torch.softmax(s, -1), 1e-2, "softmax")
+    dp = rnd(2, 50, 777, seed=9)
+    pr = p.float().cpu()
+    ref = pr * (dp - (dp * pr).sum(-1, keepdim=True)) * 0.25
+    check(ops.softmax_bwd(p, dp.to(dev), 0.25).float().cpu(), ref, 1e-2, "softmax bwd")
+
+
+CONV_CASES = [
+    # (N, Cin, Cout, dims, kernel, stride, padding)
+    (1, 32, 32, (8, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 64, 96, (5, 9, 11), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 96, 32, (4, 8, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 1, 32, (8, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 32, 1, (8, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 8, 8, (4, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    (1, 96, 64, (4, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
+    (2, 32, 32, (8, 8, 8), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (1, 64, 64, (6, 10, 12), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (1, 32, 32, (8, 8, 4), (3, 3, 1), (2, 2, 1), (1, 1, 0)),
+    (2, 32, 64, (1, 16, 16), (1, 3, 3), (1, 1, 1), (0, 1, 1)),
+    (1, 64, 64, (1, 20, 12), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
+    (1, 16, 48, (4, 6, 6), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 256, 128, (4, 4, 4), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"n{c[0]}_{c[1]}to{c[2]}_{'x'.join(map(str, c[3]))}_k{c[4][0]}{c[4][2]}s{c[5][0]}{c[5][2]}")
+def test_conv_fwd_dgrad_wgrad(ops, case):
+    n, cin, cout, dims, k, s, p = case
+    x = rnd(n, cin, *dims)
+    w = rnd(cout, cin, *k, scale=1.0 / math.sqrt(cin * k[0] * k[1] * k[2]))
+    bias = rnd(cout, seed=3)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv3d(xr, wr, bias, stride=s, padding=p)
+    g = rnd(*y.shape, seed=4)
+    y.backward(g)
+    plan = ops.ConvPlan(n, dims, cin, cout, k, s, p)
+    assert plan.out_dims == tuple(y.shape[2:])
+    plan.pack(w.to(dev))
+    xc, gc = cl(x), cl(g)
+    check(cf(plan.fwd(xc, addvec=bias.to(dev))), y.detach(), 1e-2, "conv fwd")
+    check(cf(plan.dgrad(gc)), xr.grad, 1e-2, "conv dgrad")
+    dw = torch.ones_like(w).to(dev)  # wgrad accumulates
+    plan.wgrad(xc, gc, dw)
+    check(dw.cpu() - 1, wr.grad, 1e-2, "conv wgrad")
+
+
+def test_conv_fused_prologue_epilogue(ops):
+    """GroupNorm-affine + SiLU prologue, per-sample add vector (bias + temb) and residual in the epilogue."""
+    n, cin, cout, dims = 2, 64, 32, (4, 8, 8)
+    x = rnd(n, cin, *dims, scale=1.3) + 0.2
+    x = x.bfloat16().float()
+    w = rnd(cout, cin, 3, 3, 3, scale=1 / math.sqrt(27 * cin))
+    gamma, beta = 1 + 0.2 * rnd(cin, seed=5), 0.1 * rnd(cin, seed=6)
+    addv, res = rnd(n, cout, seed=7), rnd(n, cout, *dims, seed=8)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    act = F.silu(F.group_norm(xr, 32, gamma, beta, 1e-6))
+    act.retain_grad()
+    y = F.conv3d(act, wr, None, padding=1) + addv[:, :, None, None, None] + res
+    g = rnd(*y.shape, seed=9)
+    y.backward(g)
+    plan = ops.ConvPlan(n, dims, cin, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    plan.pack(w.to(dev))
+    xc = cl(x)
+    st = ops.gn_stats(xc, 32, 1e-6, gamma.to(dev), beta.to(dev))
+    check(cf(plan.fwd(xc, st, True, addvec=addv.to(dev), res=cl(res))), y.detach(), 1e-2, "fused fwd")
+    dw = torch.zeros_like(w).to(dev)
+    plan.wgrad(xc, cl(g), dw, st, True)
+    check(dw.cpu(), wr.grad, 1e-2, "fused wgrad")
+    check(cf(plan.dgrad(cl(g))), act.grad, 1e-2, "dgrad wrt activated input")
+
+
+def test_train_glue(ops):
+    from medical_image_generation_amd._lib import call, ptr
+    n, c, dims = 2, 4, (3, 4, 5)
+    v = 60
+    x0, noise = rnd(n, c, *dims), rnd(n, c, *dims, seed=1)
+    acp = torch.cumprod(1 - torch.linspace(0.0015 ** 0.5, 0.0205 ** 0.5, 1000) ** 2, 0)
+    t = torch.tensor([3, 900])
+    out = torch.empty((n, *dims, c), dtype=torch.bfloat16, device=dev)
+    sa, so = acp.sqrt().to(dev), (1 - acp).sqrt().to(dev)
+    x0d, nd, td = x0.to(dev), noise.to(dev), t.to(dev)  # keep alive: calls are asynchronous
+    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(out), n, c, v)
+    ref = acp[t].sqrt().view(n, 1, 1, 1, 1) * x0 + (1 - acp[t]).sqrt().view(n, 1, 1, 1, 1) * noise
+    check(cf(out), ref, 1e-2, "qsample")
+    pred = rnd(n, c, *dims, seed=2)
+    pr = pred.clone().requires_grad_(True)
+    loss_ref = F.mse_loss(pr, noise)
+    loss_ref.backward()
+    loss, dpred = torch.zeros(1, device=dev), torch.empty_like(out)
+    predd = cl(pred)
+    call("mi_mse_fwd_bwd", ptr(predd), ptr(nd), ptr(dpred), ptr(loss), n, c, v, 1.0)
+    check(loss.cpu(), loss_ref.detach().reshape(1), 1e-4, "mse loss")
+    check(cf(dpred), pr.grad, 1e-2, "mse grad")
+
+
+@pytest.mark.parametrize("decoupled,wd", [(1, 0.01), (0, 0.0), (0, 0.1)])
+def test_adam_matches_torch(ops, decoupled, wd):
+    from medical_image_generation_amd._lib import call, ptr
+    n = 10007
+    p0 = torch.randn(n)
+    grads = [torch.randn(n) * (3.0 if i == 0 else 0.01) for i in range(3)]
+    pr = p0.clone().requires_grad_(True)
+    opt = (torch.optim.AdamW([pr], lr=1e-3, weight_decay=wd) if decoupled else torch.optim.Adam([pr], lr=1e-3, weight_decay=wd))
+    p, m, v = p0.clone().to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    step, sumsq = torch.zeros(1, device=dev), torch.zeros(1, device=dev)
+    for g in grads:
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        gd = g.clone().to(dev)
+        call("mi_sumsq_f32", ptr(gd), n, ptr(sumsq), 0)
+        call("mi_adam_step", ptr(p), ptr(gd), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled, ptr(sumsq), 1.0, ptr(step))
+    assert float(step) == 3.0
+    check(p.cpu(), pr.detach(), 1e-5, "adam params")
