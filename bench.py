@@ -1,0 +1,176 @@
+"""bench.py -- train-step voxels/sec of the 3-D DDPM U-Net at 128^3 bf16 on N MI355X (BASELINE.json metric).
+
+One JSON line on rank 0 (contract in the task statement).  A "step" = noise -> q-sample -> UNet forward -> MSE ->
+backward -> (gradient all-reduce) -> clip_grad_norm_ -> AdamW on one synthetic batch already resident in HBM.
+  python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# C4 of SURVEY 8d / BASELINE.json configs[3]; configs[1] (C2) is the same net at 96^3, batch 2
+C4 = dict(spatial_dims=3, in_channels=1, out_channels=1, num_res_blocks=2, num_channels=(32, 64, 128, 256),
+          attention_levels=(False, False, False, True), num_head_channels=(0, 0, 0, 64), norm_num_groups=32,
+          strides=[[1] * 3] + [[2] * 3] * 3, kernel_sizes=[[3] * 3] * 4, paddings=[[1] * 3] * 4)
+MFMA_PEAK_BF16 = 2.5e15  # dense, MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def synthetic_volume(shape, seed, device):
+    """uniform [0,1) inside a centred ellipsoid, 0 outside (NIfTI-like intensity volume)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.rand(shape, generator=g)
+    grids = torch.meshgrid(*[torch.linspace(-1, 1, s) for s in shape[2:]], indexing="ij")
+    return (x * (sum(v ** 2 for v in grids) <= 0.9)).to(device)
+
+
+def dominant_kernel_roofline(size, iters=20):
+    """The most-launched kernel of the step: k3 s1 32->32 implicit-GEMM conv at full resolution (7 forward + 7 dgrad
+    launches per step).  HIP-event timing on the launch stream; algorithmic flops = 2 * voxels * 32 * 32 * 27."""
+    from medical_image_generation_amd import hipops as ops
+    dev = torch.device("cuda")
+    x = torch.randn((1, size, size, size, 32), device=dev).to(torch.bfloat16)
+    w = torch.randn((32, 32, 3, 3, 3), device=dev) / 30
+    plan = ops.ConvPlan(1, (size,) * 3, 32, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    plan.pack(w)
+    for _ in range(3):
+        plan.fwd(x)
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(iters):
+        plan.fwd(x)
+    e1.record(st)
+    e1.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / iters
+    flops = 2.0 * size ** 3 * 32 * 32 * 27
+    return {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+            "frac": flops / sec / MFMA_PEAK_BF16, "traffic": None, "kernel": "k_conv_igemm<1,2,10> (k3 s1 32->32 @%d^3)" % size,
+            "avg_launch_us": sec * 1e6}
+
+
+def cpu_baseline(size=48):
+    """The oracle (CPU restatement of the reference, fp32) timed on this host: one full train step of the SAME net on a
+    smaller crop (bounded to ~10-30 s)."""
+    from oracle import nets, step
+    torch.set_num_threads(os.cpu_count() or 1)
+    net = nets.DiffusionModelUNet(**C4)
+    for n, p in net.named_parameters():  # un-zero the zero_module'd convs so the backward is not trivially sparse
+        if float(p.abs().max()) == 0:
+            torch.nn.init.normal_(p, std=0.02)
+    opt = torch.optim.AdamW(net.parameters(), lr=2e-5)
+    sched = step.DDPMSchedule()
+    x0 = torch.rand(1, 1, size, size, size)
+    t0 = time.perf_counter()
+    step.ddpm_train_step(net, opt, sched, x0, torch.randn_like(x0), torch.tensor([500]))
+    dt = time.perf_counter() - t0
+    return {"value": size ** 3 / dt, "unit": "voxels/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 full train step (fwd+bwd+clip+AdamW) of the C4 U-Net on one {size}^3 crop, fp32, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=1, help="per-GPU batch")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from medical_image_generation_amd.trainer import DDPMTrainer
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    torch.manual_seed(42)  # identical initial weights on every rank
+    net = DiffusionModelUNet(**C4)
+    for n, p in net.named_parameters():
+        if float(p.abs().max()) == 0:  # zero_module'd tensors: randomise (otherwise half the backward sees zeros)
+            torch.nn.init.normal_(p, std=0.02)
+    net = net.to(dev)
+    tr = DDPMTrainer(net, lr=2e-5, optimizer="AdamW", max_grad_norm=1.0, device=dev)
+    shape = (args.batch, 1, args.size, args.size, args.size)
+    x0 = synthetic_volume(shape, 42 + rank, dev)
+    gen = torch.Generator(device=dev).manual_seed(42 + rank)
+    noise = torch.empty(shape, device=dev)
+    t = torch.empty(args.batch, dtype=torch.int64, device=dev)
+
+    use_graph = not args.no_graph
+    noise.normal_(generator=gen), t.random_(0, 1000, generator=gen)
+    if use_graph:
+        tr.capture(x0, noise, t)
+        _, noise, t = tr._static  # the graphs read these buffers: fresh noise / timesteps are drawn INTO them each step
+
+    def one_step(use_graph):
+        noise.normal_(generator=gen)
+        t.random_(0, 1000, generator=gen)
+        return tr.step_graph() if use_graph else tr.step(x0, noise, t)
+
+    for _ in range(args.warmup):
+        one_step(use_graph)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step(use_graph)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    voxels = world * args.batch * args.size ** 3 * args.steps
+
+    if rank == 0:
+        # algorithmic flops of one step of this model (engine counters: 2*MACs, bwd = dgrad + wgrad)
+        from medical_image_generation_amd import engine as E
+        c = E.Ctx(tr.arena, net._plans, grad_enabled=True)
+        net._run(c, torch.zeros((args.batch, args.size, args.size, args.size, 1), dtype=torch.bfloat16, device=dev), t, need_dx=False)
+        c.tape.fns.clear()
+        step_flops = c.flops_fwd + c.flops_bwd
+        del c
+        roof = dominant_kernel_roofline(args.size)
+        out = {
+            "metric": "3D DDPM U-Net train-step voxels/sec at 128^3 bf16", "value": voxels / dt, "unit": "voxels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"C4: DiffusionModelUNet num_channels=(32,64,128,256), attention at 16^3 (heads of 64), "
+                                   f"{args.size}^3 x batch {args.batch}/GPU, eps-prediction, AdamW, clip 1.0",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "hipgraph": use_graph},
+            "model_flops_per_step": step_flops,
+            "step_mfma_frac": step_flops / (dt / args.steps) / MFMA_PEAK_BF16,
+            "loss": float(loss),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -71,16 +71,19 @@ int mi_conv_plan_out_dims(const mi_conv_plan* plan, int* dims3);
 /* fp32 master weight (torch layout) -> packed bf16 MFMA fragments for forward and data-gradient; call after every update */
 int mi_conv_pack_weights(mi_conv_plan* plan, const float* weight, hipStream_t stream);
 /* y = conv(act(x)) + addvec + res;  act = GroupNorm affine (+SiLU) applied on the fly when scale_shift != NULL;
- * addvec: fp32 [Cout] (bias) or [N][Cout] (bias + time-embedding projection, UNet:692-695) */
+ * addvec: fp32 [Cout] (addvec_stride 0: bias) or N rows of pitch addvec_stride (bias + time-embedding projection, UNet:692-695) */
 int mi_conv_fwd(mi_conv_plan* plan, const void* x, int x_cstride, const float* scale_shift, int silu, const float* addvec,
-                int addvec_per_n, const void* res, int res_cstride, void* y, int y_cstride, hipStream_t stream);
+                int addvec_stride, const void* res, int res_cstride, void* y, int y_cstride, hipStream_t stream);
 /* dx = conv_transpose(dy)  (gradient w.r.t. the ACTIVATED input) */
 int mi_conv_dgrad(mi_conv_plan* plan, const void* dy, int dy_cstride, void* dx, int dx_cstride, hipStream_t stream);
 /* dweight += x_act^T * dy   (fp32, torch layout; x_act recomputed from x with the same fused prologue) */
 int mi_conv_wgrad(mi_conv_plan* plan, const void* x, int x_cstride, const float* scale_shift, int silu, const void* dy, int dy_cstride,
                   float* dweight, hipStream_t stream);
-/* out[n][c] (+)= sum_v x[n][v][c]  (bias / time-embedding gradients) */
-int mi_colsum_bf16(const void* x, float* out, int N, int64_t V, int C, int accumulate, hipStream_t stream);
+/* out[n*out_stride + c] (+)= sum_v x[n][v][c]  (bias / time-embedding gradients) */
+int mi_colsum_bf16(const void* x, float* out, int out_stride, int N, int64_t V, int C, int accumulate, hipStream_t stream);
+/* tiny fp32 helpers for bias / embedding vectors: y[r][c] += x[r][c];  out[c] (+)= sum_r in[r][c] */
+int mi_add_f32_2d(const float* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t stream);
+int mi_sum_rows_f32(const float* in, int ld, int rows, int cols, float* out, int accumulate, hipStream_t stream);
 
 /* ---- aten::mm/addmm/bmm/baddbmm + _softmax (+backward): nn.Linear (UNet:379-381,646,1832-1834), AttentionBlock._attention
  *      (UNet:406-416, AEKL:271-281).  C[z] = alpha*A[z]*B[z]^T (+bias[n]) (+R[z]);  z -> (z/Z2, z%Z2) two-level batch strides -- */

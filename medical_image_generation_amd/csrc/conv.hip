@@ -60,7 +60,7 @@ struct ConvArgs {
   const int* taps;              // LDS byte offsets
   int nchunks;
   const float* ss; int ss_C; int pro_silu;  // prologue affine [N][ss_C][2] (channel = src channel % ss_C) or null
-  const float* addvec; int addvec_per_n;    // [N][Cout] / [Cout] fp32 or null
+  const float* addvec; int addvec_stride;   // fp32 [Cout] (stride 0) or [N] rows of pitch `stride`; null = none
   const bf16* res; int res_cs;
   Geom g;
 };
@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a) {
         for (int i = 0; i < 4; ++i) v[i] = acc[vb][cb][grp * 4 + i];
         const bool full = (co + 4 <= cls_lim) && ((a.y_cs & 3) == 0);
         if (a.addvec) {
-          const float* av = a.addvec + (a.addvec_per_n ? (int64_t)n * a.Cout : 0) + co;
+          const float* av = a.addvec + (int64_t)n * a.addvec_stride + co;
 #pragma unroll
           for (int i = 0; i < 4; ++i)
             if (co + i < cls_lim) v[i] += av[i];
@@ -586,9 +586,11 @@ int launch_igemm(const ConvArgs& a, int ntiles, int ny, hipStream_t st) {
 #define MI_LAUNCH_NP(NPV)                                                                                  \
   do {                                                                                                     \
     auto kern = k_conv_igemm<NCB, VB, NPV>;                                                                \
-    if (lds > 48 * 1024) {                                                                                 \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    static int lds_ok = 0; /* raise the dynamic-LDS limit once per instantiation (not a stream op) */      \
+    if ((int)lds > lds_ok) {                                                                               \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (e != hipSuccess) return (int)e;                                                                  \
+      lds_ok = 160 * 1024;                                                                                 \
     }                                                                                                      \
     hipLaunchKernelGGL(kern, grid, blk, lds, st, a);                                                       \
   } while (0)
@@ -707,7 +709,7 @@ int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
   return 0;
 }
 
-int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const float* addvec, int addvec_per_n,
+int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const float* addvec, int addvec_stride,
                 const void* res, int res_cs, void* y, int y_cs, hipStream_t st) {
   if (!P || !x || !y || x_cs < P->Cin || y_cs < P->Cout) return MI_ERR_BAD_ARG;
   ConvArgs a;
@@ -727,7 +729,7 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
   a.ogpq = P->fwd.ny; a.outc_q = P->Cout;
   a.wpk = P->fwd.d_wpk; a.hdr = P->fwd.d_hdr; a.taps = P->fwd.d_taps; a.nchunks = P->fwd.nchunks;
   a.ss = scale_shift; a.ss_C = P->Cin; a.pro_silu = silu;
-  a.addvec = addvec; a.addvec_per_n = addvec_per_n;
+  a.addvec = addvec; a.addvec_stride = addvec_stride;
   a.res = (const bf16*)res; a.res_cs = res_cs;
   a.g = P->g_fwd;
   int ntiles = P->N * a.g.tilesD * a.g.tilesH * a.g.tilesW;
@@ -794,9 +796,11 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
 #define MI_LAUNCH_WG(NPV)                                                                                          \
   do {                                                                                                             \
     auto kern = k_conv_wgrad<NPV, 4, 7>;                                                                           \
-    if (lds > 48 * 1024) {                                                                                         \
-      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    static int lds_ok = 0;                                                                                         \
+    if ((int)lds > lds_ok) {                                                                                       \
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       if (e != hipSuccess) return (int)e;                                                                          \
+      lds_ok = 160 * 1024;                                                                                         \
     }                                                                                                              \
     hipLaunchKernelGGL(kern, grid, blk, lds, st, w);                                                               \
   } while (0)

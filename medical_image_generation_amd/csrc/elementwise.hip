@@ -196,7 +196,7 @@ __global__ void k_silu_bwd_f32(const float* x, const float* dy, float* dx, int64
 // ---------------------------------------------------------------- column sums: out[n][c] (+)= sum_v x[n][v][c]
 // grid (chunks, N); one block reduces a V-range for all C channels; partial results are added with fp32 atomics
 // (C floats per block -> a few thousand atomics per call, far below the atomic rate).
-__global__ void k_colsum(const bf16* __restrict__ x, float* __restrict__ out, int C, int64_t V, int64_t vchunk) {
+__global__ void k_colsum(const bf16* __restrict__ x, float* __restrict__ out, int out_stride, int C, int64_t V, int64_t vchunk) {
   extern __shared__ float sm[];  // [rows][C]
   int n = blockIdx.y;
   int C8 = C / 8;
@@ -219,8 +219,38 @@ __global__ void k_colsum(const bf16* __restrict__ x, float* __restrict__ out, in
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float s = 0.f;
     for (int k = 0; k < rows; ++k) s += sm[k * C + c];
-    atomicAdd(out + (int64_t)n * C + c, s);
+    atomicAdd(out + (int64_t)n * out_stride + c, s);
   }
+}
+
+// ragged channel counts (C = 1, 4, ...; the 1-channel output conv): one pass per channel, block reduce + one atomic
+__global__ void __launch_bounds__(256) k_colsum_ragged(const bf16* __restrict__ x, float* __restrict__ out, int out_stride, int C,
+                                                       int64_t V, int64_t vchunk) {
+  __shared__ float red[4];
+  int n = blockIdx.y;
+  int64_t v0 = blockIdx.x * vchunk, v1 = v0 + vchunk < V ? v0 + vchunk : V;
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.f;
+    for (int64_t v = v0 + threadIdx.x; v < v1; v += 256) acc += bf2f(x[((int64_t)n * V + v) * C + c]);
+    float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(out + (int64_t)n * out_stride + c, s);
+  }
+}
+
+// y[r][c] += x[r][c] over a [rows][cols] block with row pitches ldx / ldy  (fp32; tiny tensors: biases, embeddings)
+__global__ void k_add_f32_2d(const float* x, int ldx, float* y, int ldy, int rows, int cols) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  int r = i / cols, c = i - r * cols;
+  y[(int64_t)r * ldy + c] += x[(int64_t)r * ldx + c];
+}
+// out[c] (+)= sum_r in[r][c]
+__global__ void k_sum_rows_f32(const float* in, int ld, int rows, int cols, float* out, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = accumulate ? out[c] : 0.f;
+  for (int r = 0; r < rows; ++r) s += in[(int64_t)r * ld + c];
+  out[c] = s;
 }
 
 }  // namespace
@@ -338,11 +368,18 @@ int mi_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, hipSt
   MI_CHECK_LAUNCH();
   return 0;
 }
-int mi_colsum_bf16(const void* x, float* out, int N, int64_t V, int C, int accumulate, hipStream_t st) {
-  if (C & 7 || C > 2048 || N <= 0 || V <= 0) return MI_ERR_BAD_ARG;
+int mi_colsum_bf16(const void* x, float* out, int out_stride, int N, int64_t V, int C, int accumulate, hipStream_t st) {
+  if (C <= 0 || C > 8192 || N <= 0 || V <= 0 || out_stride < C) return MI_ERR_BAD_ARG;
   if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)N * C, st);
+    hipError_t e = hipMemset2DAsync(out, sizeof(float) * (size_t)out_stride, 0, sizeof(float) * (size_t)C, (size_t)N, st);
     if (e != hipSuccess) return (int)e;
+  }
+  if (C & 7) {
+    if (C > 64) return MI_ERR_UNSUPPORTED;
+    int64_t vc = 8192;
+    hipLaunchKernelGGL(k_colsum_ragged, dim3(ceil_div(V, vc), N), dim3(256), 0, st, (const bf16*)x, out, out_stride, C, V, vc);
+    MI_CHECK_LAUNCH();
+    return 0;
   }
   int C8 = C / 8;
   int threads = 256;
@@ -350,7 +387,19 @@ int mi_colsum_bf16(const void* x, float* out, int N, int64_t V, int C, int accum
   int rows = threads / C8;
   int64_t vchunk = 2048;
   int chunks = ceil_div(V, vchunk);
-  hipLaunchKernelGGL(k_colsum, dim3(chunks, N), dim3(threads), sizeof(float) * (size_t)rows * C, st, (const bf16*)x, out, C, V, vchunk);
+  hipLaunchKernelGGL(k_colsum, dim3(chunks, N), dim3(threads), sizeof(float) * (size_t)rows * C, st, (const bf16*)x, out, out_stride, C, V, vchunk);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_add_f32_2d(const float* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_add_f32_2d, dim3(ceil_div((int64_t)rows * cols, 256)), dim3(256), 0, st, x, ldx, y, ldy, rows, cols);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_sum_rows_f32(const float* in, int ld, int rows, int cols, float* out, int accumulate, hipStream_t st) {
+  if (rows <= 0 || cols <= 0) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_sum_rows_f32, dim3(ceil_div(cols, 256)), dim3(256), 0, st, in, ld, rows, cols, out, accumulate);
   MI_CHECK_LAUNCH();
   return 0;
 }

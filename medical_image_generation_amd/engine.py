@@ -1,0 +1,327 @@
+"""Tape engine: forward ops on channels-last bf16 activations that record their own HIP backward.
+
+Why not one torch.autograd.Function per kernel: the fused kernels need to know about each other
+(GroupNorm statistics feed the NEXT conv's prologue; the conv's data gradient feeds the GroupNorm/SiLU
+backward which also folds in the other gradient branches of the same tensor), and gradient accumulation
+must run through our kernels, not aten::add.  The tape gives that control; `functional.py` wraps whole
+blocks / networks of it as torch.autograd.Function for callers that want autograd.
+
+Everything here launches HIP kernels through hipops; torch only allocates (torch.empty / views).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import hipops as ops
+from ._lib import call, ptr
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+# --------------------------------------------------------------------------------------------- parameters
+class ParamArena:
+    """All parameters of a network in ONE flat fp32 buffer (+ one for gradients), in an order chosen so that tensors
+    the kernels want fused are adjacent (q/k/v weights -> one [3C, C] matrix; every time_emb_proj -> one GEMM).
+    The trainable prefix [0, n_trainable) is what the fused optimizer / DDP all-reduce touch; statically unused
+    tensors (`proj_attn.*`, never called: UNet:383 vs 418-458) sit behind it and are never updated -- the same
+    outcome as torch.optim skipping parameters whose grad is None."""
+
+    def __init__(self, entries, device):
+        # entries: list of (name, shape, trainable)
+        self.offsets, self.shapes = {}, {}
+        off = 0
+        for trainable_pass in (True, False):
+            for name, shape, trainable in entries:
+                if trainable != trainable_pass:
+                    continue
+                n = math.prod(shape)
+                self.offsets[name], self.shapes[name] = off, tuple(shape)
+                off += n
+                if not trainable_pass or n % 4:
+                    off = (off + 3) // 4 * 4
+            if trainable_pass:
+                off = (off + 3) // 4 * 4
+                self.n_trainable = off
+        self.numel = max(off, 4)
+        self.data = torch.zeros(self.numel, dtype=F32, device=device)
+        self.grad = torch.zeros(self.numel, dtype=F32, device=device)
+
+    def view(self, name, flat=None):
+        flat = self.data if flat is None else flat
+        o, s = self.offsets[name], self.shapes[name]
+        return flat[o:o + math.prod(s)].view(s)
+
+    def gview(self, name):
+        return self.view(name, self.grad)
+
+    def span(self, names, flat=None):
+        """Contiguous view covering consecutive tensors `names` (asserts adjacency)."""
+        flat = self.data if flat is None else flat
+        o = self.offsets[names[0]]
+        end = o
+        for nme in names:
+            assert self.offsets[nme] == end, f"{nme} is not adjacent in the arena"
+            end += math.prod(self.shapes[nme])
+        return flat[o:end]
+
+
+# --------------------------------------------------------------------------------------------- tape
+class Tape:
+    def __init__(self):
+        self.fns = []
+        self.grads = {}
+        self.keep = []  # tensors whose id() is used as a key must stay alive
+
+    def record(self, fn):
+        self.fns.append(fn)
+
+    def take(self, t):
+        return self.grads.pop(id(t), None)
+
+    def put(self, t, g):
+        """grad(t) += g through our add kernel."""
+        cur = self.grads.get(id(t))
+        self.grads[id(t)] = g if cur is None else ops.add(cur, g)
+        self.keep.append(t)
+
+    def backward(self, out, dout):
+        self.put(out, dout)
+        for fn in reversed(self.fns):
+            fn()
+        self.fns.clear()
+
+
+class Ctx:
+    """One forward/backward of one network: parameter views, plan cache, tape."""
+
+    def __init__(self, arena: ParamArena, plans: dict, grad_enabled=True):
+        self.arena, self.plans = arena, plans
+        self.tape = Tape() if grad_enabled else None
+        self.packed = set()
+        # algorithmic matmul-class flops of this pass (2*MACs; torch.utils.flop_counter convention)
+        self.flops_fwd = 0
+        self.flops_bwd = 0
+
+    def count(self, fwd_flops, dgrad=True, wgrad=True):
+        self.flops_fwd += fwd_flops
+        if self.tape is not None:
+            self.flops_bwd += fwd_flops * (int(dgrad) + int(wgrad))
+
+    def p(self, name):
+        return self.arena.view(name)
+
+    def g(self, name):
+        return self.arena.gview(name)
+
+
+# --------------------------------------------------------------------------------------------- ops
+def gn(ctx: Ctx, x, name, groups, eps):
+    """Statistics only; the affine(+SiLU) is applied by the consumer (conv prologue or gn_apply)."""
+    st = ops.gn_stats(x, groups, eps, ctx.p(name + ".weight"), ctx.p(name + ".bias"))
+    st.name = name
+    return st
+
+
+def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addvec=None, res=None, d_addvec=None,
+         need_dx=True):
+    """y = conv(act(x)) + addvec + res   (weight `name.weight`, bias folded into addvec by the caller or taken from
+    `name.bias` when addvec is None).  norm: GNStats of x for the fused prologue.  d_addvec: fp32 [N, Cout] view that
+    receives the per-sample column sums of dy (time-embedding gradient) in backward."""
+    n, d, h, w, cin = x.shape
+    wt = ctx.p(name + ".weight")
+    cout = wt.shape[0]
+    key = (name, n, d, h, w)
+    plan = ctx.plans.get(key)
+    if plan is None:
+        plan = ctx.plans[key] = ops.ConvPlan(n, (d, h, w), cin, cout, kernel, stride, padding)
+    if key not in ctx.packed:
+        plan.pack(wt)  # [Cout, Cin, (kd,) kh, kw] contiguous: same memory layout for 2-D and 3-D nets
+        ctx.packed.add(key)
+    av = addvec if addvec is not None else ctx.p(name + ".bias")
+    y = plan.fwd(x, norm, silu, addvec=av, res=res)
+    ctx.count(2 * y.numel() * cin * math.prod(kernel), dgrad=need_dx)
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is None:
+                return
+            gw = ctx.g(name + ".weight")
+            plan.wgrad(x, dy, gw, norm, silu)
+            gb = ctx.g(name + ".bias")
+            if d_addvec is not None:  # per-sample sums -> temb gradient; bias gradient = their sum over n
+                ops.colsum(dy, out=d_addvec, accumulate=False)
+                ops.sum_rows_f32(d_addvec, gb, accumulate=True)
+            else:
+                ops.colsum(dy, out=gb.view(1, cout), accumulate=True, merge_batch=True)
+            if res is not None:
+                tape.put(res, dy)
+            if need_dx:
+                g = plan.dgrad(dy)
+                if norm is not None:
+                    other = tape.take(x)
+                    dx = ops.gn_bwd(g, x, norm, ctx.p(norm.name + ".weight"), silu, ctx.g(norm.name + ".weight"),
+                                    ctx.g(norm.name + ".bias"), add=other)
+                    tape.grads[id(x)] = dx
+                    tape.keep.append(x)
+                else:
+                    tape.put(x, g)
+
+        tape.record(bwd)
+    return y
+
+
+def upsample(ctx: Ctx, x, factors):
+    y = ops.upsample_nearest(x, factors)
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is not None:
+                tape.put(x, ops.upsample_nearest_bwd(dy, factors))
+
+        tape.record(bwd)
+    return y
+
+
+def concat(ctx: Ctx, a, b):
+    y = ops.concat_channels(a, b)
+    if ctx.tape is not None:
+        tape = ctx.tape
+        ca, cb = a.shape[-1], b.shape[-1]
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is not None:
+                tape.put(a, ops.slice_channels(dy, 0, ca))
+                tape.put(b, ops.slice_channels(dy, ca, cb))
+
+        tape.record(bwd)
+    return y
+
+
+def _gemm(a, lda, sa1, sa2, b, ldb, sb1, sb2, c, ldc, sc1, sc2, m, n, k, z, z2, alpha=1.0, bias=None, res=None, ldr=0, sr1=0,
+          sr2=0, accumulate=False):
+    """Raw pointer-level NT GEMM: a/b/c/res are (tensor, element_offset) pairs or tensors."""
+
+    def addr(t):
+        if t is None:
+            return None
+        if isinstance(t, tuple):
+            return t[0].data_ptr() + t[1] * t[0].element_size()
+        return t.data_ptr()
+
+    ct = c[0] if isinstance(c, tuple) else c
+    call("mi_gemm_nt_bf16", addr(a), lda, sa1, sa2, addr(b), ldb, sb1, sb2, addr(c), ldc, sc1, sc2, ptr(bias), addr(res), ldr, sr1, sr2,
+         m, n, k, z, z2, float(alpha), int(ct.dtype == F32), int(accumulate))
+
+
+def _transpose(src, ld_in, si1, si2, rows, cols, z, z2, device):
+    """[z][rows][cols] (strided) -> contiguous [z][cols][rows]."""
+    out = torch.empty((z, cols, rows), dtype=BF16, device=device)
+    a = src[0].data_ptr() + src[1] * 2 if isinstance(src, tuple) else src.data_ptr()
+    call("mi_transpose_bf16", a, ld_in, si1, si2, ptr(out), rows, z2 * cols * rows, cols * rows, rows, cols, z, z2)
+    return out
+
+
+def attention(ctx: Ctx, x, name, groups, eps, heads):
+    """AttentionBlock.forward (UNet:418-458 / AEKL:283-323): GN -> q,k,v -> softmax(QK^T/sqrt(d)) V -> + x.  No out-proj.
+    Channels-last makes the reference's [B,C,S]->[B,S,C] transpose free."""
+    b, d_, h_, w_, c = x.shape
+    s = d_ * h_ * w_
+    hd = c // heads
+    scale = 1.0 / math.sqrt(c / heads)
+    dev = x.device
+    st = gn(ctx, x, name + ".norm", groups, eps)
+    xn = ops.gn_apply(x, st, False)                                              # [B, S, C]
+    wqkv = ops.cast_bf16(ctx.arena.span([f"{name}.to_{t}.weight" for t in "qkv"]).view(3 * c, c))
+    bqkv = ctx.arena.span([f"{name}.to_{t}.bias" for t in "qkv"])
+    qkv = torch.empty((b * s, 3 * c), dtype=BF16, device=dev)
+    _gemm(xn, c, 0, 0, wqkv, c, 0, 0, qkv, 3 * c, 0, 0, b * s, 3 * c, c, 1, 1, bias=bqkv)
+    z = b * heads
+    sq = s * 3 * c  # batch stride of qkv
+    scores = torch.empty((z, s, s), dtype=F32, device=dev)
+    _gemm((qkv, 0), 3 * c, sq, hd, (qkv, c), 3 * c, sq, hd, scores, s, heads * s * s, s * s, s, s, hd, z, heads, alpha=scale)
+    probs = ops.softmax_fwd(scores)
+    del scores
+    vt = _transpose((qkv, 2 * c), 3 * c, sq, hd, s, hd, z, heads, dev)            # [z, hd, S]
+    y = torch.empty_like(x)
+    _gemm(probs, s, heads * s * s, s * s, vt, s, heads * hd * s, hd * s, (y, 0), c, s * c, hd, s, hd, s, z, heads,
+          res=(x, 0), ldr=c, sr1=s * c, sr2=hd)
+    ctx.count(2 * b * s * c * 3 * c)       # q, k, v projections
+    ctx.count(4 * b * s * s * c)           # QK^T and PV
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is None:
+                return
+            dp = torch.empty((z, s, s), dtype=F32, device=dev)
+            _gemm((dy, 0), c, s * c, hd, (qkv, 2 * c), 3 * c, sq, hd, dp, s, heads * s * s, s * s, s, s, hd, z, heads)
+            ds = ops.softmax_bwd(probs, dp, scale)
+            del dp
+            dqkv = torch.empty((b * s, 3 * c), dtype=BF16, device=dev)
+            kt = _transpose((qkv, c), 3 * c, sq, hd, s, hd, z, heads, dev)
+            _gemm(ds, s, heads * s * s, s * s, kt, s, heads * hd * s, hd * s, (dqkv, 0), 3 * c, sq, hd, s, hd, s, z, heads)
+            qt = _transpose((qkv, 0), 3 * c, sq, hd, s, hd, z, heads, dev)
+            dst = _transpose(ds, s, heads * s * s, s * s, s, s, z, heads, dev)
+            _gemm(dst, s, heads * s * s, s * s, qt, s, heads * hd * s, hd * s, (dqkv, c), 3 * c, sq, hd, s, hd, s, z, heads)
+            del dst, ds
+            pt = _transpose(probs, s, heads * s * s, s * s, s, s, z, heads, dev)
+            dot = _transpose((dy, 0), c, s * c, hd, s, hd, z, heads, dev)
+            _gemm(pt, s, heads * s * s, s * s, dot, s, heads * hd * s, hd * s, (dqkv, 2 * c), 3 * c, sq, hd, s, hd, s, z, heads)
+            del pt
+            # parameter gradients: dW[3C, C] += dqkv^T xn ; db += colsum(dqkv)
+            dqkv_t = _transpose(dqkv, 3 * c, 0, 0, b * s, 3 * c, 1, 1, dev)[0]   # [3C, B*S]
+            xn_t = _transpose(xn, c, 0, 0, b * s, c, 1, 1, dev)[0]               # [C, B*S]
+            gw = ctx.arena.span([f"{name}.to_{t}.weight" for t in "qkv"], ctx.arena.grad)
+            _gemm(dqkv_t, b * s, 0, 0, xn_t, b * s, 0, 0, gw, c, 0, 0, 3 * c, c, b * s, 1, 1, accumulate=True)
+            gb = ctx.arena.span([f"{name}.to_{t}.bias" for t in "qkv"], ctx.arena.grad)
+            ops.colsum(dqkv.view(1, 1, 1, b * s, 3 * c), out=gb.view(1, 3 * c), accumulate=True)
+            # input gradient through the projections and the norm, plus the residual branch
+            wqkv_t = _transpose(wqkv, c, 0, 0, 3 * c, c, 1, 1, dev)[0]           # [C, 3C]
+            dxn = torch.empty((b, d_, h_, w_, c), dtype=BF16, device=dev)
+            _gemm(dqkv, 3 * c, 0, 0, wqkv_t, 3 * c, 0, 0, dxn, c, 0, 0, b * s, c, 3 * c, 1, 1)
+            other = tape.take(x)
+            add = dy if other is None else ops.add(other, dy)
+            dx = ops.gn_bwd(dxn, x, st, ctx.p(name + ".norm.weight"), False, ctx.g(name + ".norm.weight"),
+                            ctx.g(name + ".norm.bias"), add=add)
+            tape.grads[id(x)] = dx
+            tape.keep.append(x)
+
+        tape.record(bwd)
+    return y
+
+
+def linear_f32(x_f32, w, b, gw, gb):
+    """Tiny fp32-in / fp32-out Linear on the embedding vectors (bf16 MFMA inside).  w [out, in], b [out] and their
+    gradient buffers gw, gb are fp32 arena views.  Returns (y, backward(dy) -> dx)."""
+    out_f, in_f = w.shape
+    xb, wb = ops.cast_bf16(x_f32), ops.cast_bf16(w)
+    m = x_f32.shape[0]
+    y = torch.empty((m, out_f), dtype=F32, device=x_f32.device)
+    _gemm(xb, in_f, 0, 0, wb, in_f, 0, 0, y, out_f, 0, 0, m, out_f, in_f, 1, 1, bias=b)
+
+    def bwd(dy_f32, need_dx=True):
+        """dy may be a column slice; accumulates into the weight/bias gradients, returns dx (fp32) or None."""
+        dyb = ops.cast_bf16(dy_f32)
+        ops.sum_rows_f32(dy_f32, gb, accumulate=True)
+        mp = (m + 7) // 8 * 8  # K of the weight-gradient GEMM must be a multiple of 8: zero-padded transposes
+        dy_t = torch.zeros((out_f, mp), dtype=BF16, device=dy_f32.device)
+        x_t = torch.zeros((in_f, mp), dtype=BF16, device=dy_f32.device)
+        call("mi_transpose_bf16", ptr(dyb), out_f, 0, 0, ptr(dy_t), mp, 0, 0, m, out_f, 1, 1)
+        call("mi_transpose_bf16", ptr(xb), in_f, 0, 0, ptr(x_t), mp, 0, 0, m, in_f, 1, 1)
+        _gemm(dy_t, mp, 0, 0, x_t, mp, 0, 0, gw, in_f, 0, 0, out_f, in_f, mp, 1, 1, accumulate=True)
+        if not need_dx:
+            return None
+        w_t = _transpose(wb, in_f, 0, 0, out_f, in_f, 1, 1, dy_f32.device)[0]   # [in, out]
+        dx = torch.empty((m, in_f), dtype=F32, device=dy_f32.device)
+        _gemm(dyb, out_f, 0, 0, w_t, out_f, 0, 0, dx, in_f, 0, 0, m, in_f, out_f, 1, 1)
+        return dx
+
+    return y, bwd

@@ -105,7 +105,7 @@ def _workspace(nbytes, device):
 
 
 class GNStats:
-    __slots__ = ("scale_shift", "mean_rstd", "groups")
+    __slots__ = ("scale_shift", "mean_rstd", "groups", "name")
 
     def __init__(self, scale_shift, mean_rstd, groups):
         self.scale_shift, self.mean_rstd, self.groups = scale_shift, mean_rstd, groups
@@ -171,8 +171,11 @@ class ConvPlan:
         n, d, h, w, c = x.shape
         assert (n, (d, h, w), c) == (self.n, self.dims, self.cin), f"plan/input mismatch {x.shape} vs {self.n, self.dims, self.cin}"
         y = torch.empty((n,) + self.out_dims + (self.cout,), dtype=BF16, device=x.device)
-        per_n = int(addvec is not None and addvec.dim() == 2)
-        call("mi_conv_fwd", self.handle, ptr(x), _cs(x), ptr(st.scale_shift) if st is not None else None, int(silu), ptr(addvec), per_n,
+        av_stride = 0
+        if addvec is not None and addvec.dim() == 2:  # [N, Cout] rows, possibly a column slice of a wider matrix
+            assert addvec.shape == (n, self.cout) and addvec.stride(1) == 1
+            av_stride = addvec.stride(0)
+        call("mi_conv_fwd", self.handle, ptr(x), _cs(x), ptr(st.scale_shift) if st is not None else None, int(silu), ptr(addvec), av_stride,
              ptr(res), _cs(res) if res is not None else 0, ptr(y), self.cout)
         return y
 
@@ -188,12 +191,36 @@ class ConvPlan:
              ptr(dweight_f32))
 
 
-def colsum(x, out=None, accumulate=False):
+def colsum(x, out=None, accumulate=False, merge_batch=False):
+    """out[n, c] (+)= sum over voxels; `out` may be a column slice of a wider fp32 matrix.  merge_batch: sum over n too."""
     n, v, c = _vox(x)
     assert x.is_contiguous()
+    if merge_batch:
+        n, v = 1, n * v
     if out is None:
         out = torch.empty((n, c), dtype=F32, device=x.device)
-    call("mi_colsum_bf16", ptr(x), ptr(out), n, v, c, int(accumulate))
+    stride = out.stride(0) if out.dim() == 2 else c
+    call("mi_colsum_bf16", ptr(x), ptr(out), stride, n, v, c, int(accumulate))
+    return out
+
+
+def add_f32_(y, x):
+    """y += x for small fp32 matrices / vectors (row pitches honoured)."""
+    y2 = y if y.dim() == 2 else y.unsqueeze(0)
+    if x.dim() == 1:  # broadcast one row over every row of y
+        assert x.shape[0] == y2.shape[1] and x.stride(0) == 1
+        ldx, xp = 0, x
+    else:
+        assert x.shape == y2.shape and x.stride(1) == 1
+        ldx, xp = x.stride(0), x
+    assert y2.stride(1) == 1
+    call("mi_add_f32_2d", ptr(xp), ldx, ptr(y2), y2.stride(0), y2.shape[0], y2.shape[1])
+    return y
+
+
+def sum_rows_f32(x, out, accumulate=True):
+    assert x.dim() == 2 and x.stride(1) == 1 and out.is_contiguous()
+    call("mi_sum_rows_f32", ptr(x), x.stride(0), x.shape[0], x.shape[1], ptr(out), int(accumulate))
     return out
 
 
@@ -263,8 +290,9 @@ def silu_bwd_f32(x, dy):
 
 
 def cast_bf16(x_f32):
+    assert x_f32.is_contiguous() and x_f32.dtype == F32
     out = torch.empty(x_f32.shape, dtype=BF16, device=x_f32.device)
-    call("mi_cast_f32_to_bf16", ptr(x_f32.contiguous()), ptr(out), x_f32.numel())
+    call("mi_cast_f32_to_bf16", ptr(x_f32), ptr(out), x_f32.numel())
     return out
 
 

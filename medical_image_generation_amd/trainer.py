@@ -1,0 +1,146 @@
+"""Fused DDPM train step on the HIP path (the hot loop of train_ldm.LDM.train_one_epoch, T-LDM:132-191, and of
+train_ddpm.DDPM.train_one_epoch, T-DDPM:175-209):
+
+    noise -> q-sample -> DiffusionModelUNet -> MSE -> backward -> (DDP all-reduce) -> clip_grad_norm_ -> Adam[W]
+
+No torch autograd and no torch compute kernels in the step: the tape engine drives our kernels directly, the
+optimizer is one fused launch over the flat parameter arena, and the whole step can be captured in a hipGraph
+(`capture=True`) and replayed, which removes the Python / launch overhead of ~600 kernel launches.
+
+Data parallelism: one process per GPU; the trainable prefix of the flat gradient arena is all-reduced
+(average) over RCCL in a few large buckets -- statically unused `proj_attn.*` tensors live outside that prefix.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import engine as E
+from ._lib import call, ptr
+
+F32 = torch.float32
+
+
+class DDPMSchedule:
+    """alphas_cumprod of generative's DDPMScheduler (closed form; see oracle/step.py for provenance)."""
+
+    def __init__(self, num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205,
+                 prediction_type="epsilon", device="cuda"):
+        if schedule == "scaled_linear_beta":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=F32) ** 2
+        elif schedule == "linear_beta":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=F32)
+        else:
+            raise ValueError(f"unknown schedule {schedule}")
+        if prediction_type != "epsilon":
+            raise NotImplementedError("only epsilon-prediction is on the HIP path (the reference's default, CFG:1012-1013)")
+        acp = torch.cumprod(1.0 - betas, dim=0)
+        self.num_train_timesteps, self.prediction_type = num_train_timesteps, prediction_type
+        self.sqrt_acp = acp.sqrt().to(device)
+        self.sqrt_1macp = (1.0 - acp).sqrt().to(device)
+
+
+class DDPMTrainer:
+    def __init__(self, model, lr=2e-5, optimizer="AdamW", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
+                 schedule: DDPMSchedule | None = None, process_group=None, bucket_mb=64, device=None):
+        self.model = model
+        self.device = torch.device(device or "cuda")
+        self.lr, self.betas, self.eps = lr, betas, eps
+        self.decoupled = optimizer == "AdamW"
+        if optimizer not in ("AdamW", "Adam"):
+            raise ValueError("optimizer must be 'Adam' or 'AdamW'")
+        self.weight_decay = (0.01 if self.decoupled else 0.0) if weight_decay is None else weight_decay  # torch defaults
+        self.max_grad_norm = max_grad_norm
+        self.schedule = schedule or DDPMSchedule(device=self.device)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
+        self.bucket_elems = bucket_mb * (1 << 20) // 4
+        self.arena = model.arena(self.device)
+        n = self.arena.n_trainable
+        self.exp_avg = torch.zeros(n, dtype=F32, device=self.device)
+        self.exp_avg_sq = torch.zeros(n, dtype=F32, device=self.device)
+        self.step_count = torch.zeros(1, dtype=F32, device=self.device)
+        self.sumsq = torch.zeros(1, dtype=F32, device=self.device)
+        self.loss = torch.zeros(1, dtype=F32, device=self.device)
+        self._graph = None
+        self._static = None
+
+    # ------------------------------------------------------------------ pieces
+    def forward_backward(self, x0, noise, timesteps):
+        """q-sample -> UNet -> MSE -> backward into the gradient arena.  x0/noise: fp32 NCDHW, timesteps: int64 [N]."""
+        m = self.model
+        a = self.arena
+        a.grad.zero_()
+        sd = m.spatial_dims
+        n, c = x0.shape[0], x0.shape[1]
+        sp = tuple(x0.shape[2:])
+        v = 1
+        for s in sp:
+            v *= s
+        dims = (1,) * (3 - sd) + sp
+        x_t = torch.empty((n,) + dims + (c,), dtype=torch.bfloat16, device=x0.device)
+        call("mi_qsample", ptr(x0), ptr(noise), ptr(self.schedule.sqrt_acp), ptr(self.schedule.sqrt_1macp), ptr(timesteps), ptr(x_t), n, c, v)
+        ctx = E.Ctx(a, m._plans, grad_enabled=True)
+        pred = m._run(ctx, x_t, timesteps, need_dx=False)
+        dpred = torch.empty_like(pred)
+        call("mi_mse_fwd_bwd", ptr(pred), ptr(noise), ptr(dpred), ptr(self.loss), n, pred.shape[-1], v, 1.0)
+        ctx.tape.backward(pred, dpred)
+        ctx.tape.grads.clear(), ctx.tape.keep.clear()
+
+    def all_reduce_grads(self):
+        if self.world <= 1:
+            return
+        g = self.arena.grad[: self.arena.n_trainable]
+        g.mul_(1.0 / self.world)  # pre-scale: sum of pre-scaled = average, no second pass
+        for o in range(0, g.numel(), self.bucket_elems):
+            dist.all_reduce(g[o:o + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.pg)
+
+    def optimizer_step(self):
+        a = self.arena
+        n = a.n_trainable
+        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
+        if clip:
+            call("mi_sumsq_f32", ptr(a.grad), n, ptr(self.sumsq), 0)
+        call("mi_adam_step", ptr(a.data), ptr(a.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n, self.lr, self.betas[0], self.betas[1],
+             self.eps, self.weight_decay, int(self.decoupled), ptr(self.sumsq) if clip else None, float(self.max_grad_norm or 0.0),
+             ptr(self.step_count))
+
+    # ------------------------------------------------------------------ one step
+    def step(self, x0, noise, timesteps):
+        """Eager step; returns the (device) loss tensor without synchronising."""
+        self.forward_backward(x0, noise, timesteps)
+        self.all_reduce_grads()
+        self.optimizer_step()
+        return self.loss
+
+    def capture(self, x0, noise, timesteps, warmup=2):
+        """Capture forward+backward and the optimizer as hipGraphs around static input buffers (the all-reduce stays
+        eager between them so RCCL is never inside a capture).  Call step_graph() afterwards."""
+        self._static = (x0.clone(), noise.clone(), timesteps.clone())
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):  # creates conv plans / workspaces (hipMalloc) outside capture
+                self.forward_backward(*self._static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb):
+            self.forward_backward(*self._static)
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt):
+            self.optimizer_step()
+        self._graph = True
+
+    def step_graph(self, x0=None, noise=None, timesteps=None):
+        assert self._graph, "call capture() first"
+        if x0 is not None:
+            self._static[0].copy_(x0)
+        if noise is not None:
+            self._static[1].copy_(noise)
+        if timesteps is not None:
+            self._static[2].copy_(timesteps)
+        self._g_fb.replay()
+        self.all_reduce_grads()
+        self._g_opt.replay()
+        return self.loss

@@ -1,0 +1,401 @@
+"""DiffusionModelUNet "with strides" on the MI355X HIP path.
+
+Drop-in for the reference class (medimgen/diffusion_model_unet_with_strides.py:1713-2021): same constructor
+keywords, same `forward(x, timesteps, ...)`, same `state_dict()` names and shapes (checkpoints round-trip), same
+ValueError conditions.  Forward and backward run entirely on hand-written HIP kernels (channels-last bf16
+activations, fp32 accumulate / statistics / gradients); PyTorch provides memory, streams and the autograd edge.
+
+Not implemented on the HIP path (raise NotImplementedError, all unused by the reference's own configs, SURVEY 2
+rows 5 and 2a): cross-attention conditioning, class embeddings, `resblock_updown`, xformers flash attention.
+"""
+from __future__ import annotations
+
+import math
+from typing import Sequence
+
+import torch
+from torch import nn
+
+from . import engine as E
+from . import hipops as ops
+
+F32 = torch.float32
+
+
+class _Tree(nn.Module):
+    """Anonymous container: gives parameters the reference's dotted state_dict names."""
+
+
+def _attach(root, dotted, tensor):
+    mod = root
+    parts = dotted.split(".")
+    for part in parts[:-1]:
+        if part not in mod._modules:
+            mod.add_module(part, _Tree())
+        mod = mod._modules[part]
+    mod.register_parameter(parts[-1], nn.Parameter(tensor))
+
+
+def _tuple_rep(v, n):
+    if isinstance(v, (list, tuple)):
+        if len(v) != n:
+            raise ValueError(f"Sequence must have length {n}, got {len(v)}.")
+        return tuple(v)
+    return (v,) * n
+
+
+def _axis3(v, sd, fill):
+    """per-axis value for our (D, H, W) convention; 2-D nets get a unit leading axis."""
+    t = _tuple_rep(v, sd)
+    return (fill,) * (3 - sd) + tuple(int(a) for a in t)
+
+
+class ParamSpec:
+    """Declares parameters (torch default initialisers, like the nn.Conv/Linear/GroupNorm the reference builds)."""
+
+    def __init__(self, root, sd):
+        self.root, self.sd = root, sd
+        self.order = []  # (name, shape, trainable) in ARENA order
+
+    def _add(self, name, t, trainable=True):
+        _attach(self.root, name, t)
+        self.order.append((name, tuple(t.shape), trainable))
+
+    def conv(self, name, cin, cout, k, zero=False):
+        k = _tuple_rep(k, self.sd)
+        w, b = torch.empty(cout, cin, *k), torch.empty(cout)
+        if zero:  # zero_module (UNet:63-69)
+            w.zero_(), b.zero_()
+        else:
+            nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+            bound = 1 / math.sqrt(cin * math.prod(k))
+            nn.init.uniform_(b, -bound, bound)
+        self._add(name + ".weight", w)
+        self._add(name + ".bias", b)
+
+    def linear(self, name, cin, cout, trainable=True):
+        w = torch.empty(cout, cin)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        bound = 1 / math.sqrt(cin)
+        self._add(name + ".weight", w, trainable)
+        self._add(name + ".bias", torch.empty(cout).uniform_(-bound, bound), trainable)
+
+    def norm(self, name, c):
+        self._add(name + ".weight", torch.ones(c))
+        self._add(name + ".bias", torch.zeros(c))
+
+    def attention(self, name, c):
+        self.norm(name + ".norm", c)
+        for n in ("to_q", "to_k", "to_v"):
+            self.linear(f"{name}.{n}", c, c)
+        self.linear(name + ".proj_attn", c, c, trainable=False)  # constructed, never called (UNet:383 vs 418-458)
+
+
+def arena_order(entries, groups):
+    """Reorder (name, shape, trainable) so that every list in `groups` is adjacent and in the given order."""
+    grouped = {n for g in groups for n in g}
+    by_name = {e[0]: e for e in entries}
+    out = []
+    for g in groups:
+        out.extend(by_name[n] for n in g)
+    out.extend(e for e in entries if e[0] not in grouped)
+    return out
+
+
+class HipModule(nn.Module):
+    """Shared plumbing: flat parameter arena on the device, conv-plan cache, autograd edge."""
+
+    def _init_plumbing(self, spec: ParamSpec, groups):
+        self._entries = arena_order(spec.order, groups)
+        self._arena = None
+        self._plans = {}
+
+    def arena(self, device) -> E.ParamArena:
+        """(Re)bind every nn.Parameter to a view of one flat device buffer; idempotent while nothing moved."""
+        params = dict(self.named_parameters())
+        a = self._arena
+        first = self._entries[0][0]
+        if a is None or a.data.device != device or params[first].data_ptr() != a.view(first).data_ptr():
+            a = E.ParamArena(self._entries, device)
+            for name, _, _ in self._entries:
+                v = a.view(name)
+                v.copy_(params[name].data)
+                params[name].data = v
+            self._arena = a
+            self._plans = {}
+        return a
+
+    def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .float(): parameters move, the arena is rebuilt lazily
+        self._arena = None
+        return super()._apply(fn, *args, **kwargs)
+
+
+class _NetFn(torch.autograd.Function):
+    """Autograd edge of a whole network: forward = tape forward, backward = tape backward on HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, module, runner, nouts, grad_enabled, x, *params):
+        dev = x.device
+        arena = module.arena(dev)
+        c = E.Ctx(arena, module._plans, grad_enabled=grad_enabled)  # (autograd disables grad mode inside forward)
+        need_dx = bool(grad_enabled and ctx.needs_input_grad[4])
+        outs_cl, extra = runner(c, x, need_dx)
+        ctx.c, ctx.module, ctx.outs_cl, ctx.need_dx, ctx.extra = c, module, outs_cl, need_dx, extra
+        ctx.sd = module.spatial_dims
+        ctx.names = [n for n, _ in module.named_parameters()]
+        outs = tuple(ops.to_channels_first(o, ctx.sd) for o in outs_cl)
+        return outs if nouts > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *douts):
+        c = ctx.c
+        arena = c.arena
+        arena.grad.zero_()
+        tape = c.tape
+        for o, do in zip(ctx.outs_cl, douts):
+            if do is not None:
+                tape.put(o, ops.to_channels_last(do.contiguous().float()))
+        for fn in reversed(tape.fns):
+            fn()
+        tape.fns.clear()
+        dx = None
+        if ctx.need_dx:
+            g = tape.take(ctx.extra["x_cl"])
+            dx = ops.to_channels_first(g, ctx.sd) if g is not None else None
+        trainable = {n for n, _, t in ctx.module._entries if t}
+        grads = tuple(arena.gview(n).clone() if n in trainable else None for n in ctx.names)
+        tape.grads.clear(), tape.keep.clear()
+        return (None, None, None, None, dx) + grads
+
+
+class DiffusionModelUNet(HipModule):
+    def __init__(
+        self,
+        spatial_dims: int,
+        in_channels: int,
+        out_channels: int,
+        num_res_blocks: Sequence[int] | int = (2, 2, 2, 2),
+        num_channels: Sequence[int] = (32, 64, 64, 64),
+        attention_levels: Sequence[bool] = (False, False, True, True),
+        norm_num_groups: int = 32,
+        norm_eps: float = 1e-6,
+        resblock_updown: bool = False,
+        num_head_channels: int | Sequence[int] = 8,
+        with_conditioning: bool = False,
+        transformer_num_layers: int = 1,
+        cross_attention_dim: int | None = None,
+        num_class_embeds: int | None = None,
+        upcast_attention: bool = False,
+        use_flash_attention: bool = False,
+        dropout_cattn: float = 0.0,
+        strides=((2, 2, 2), (2, 2, 2), (2, 2, 2)),
+        kernel_sizes=((4, 4, 4), (4, 4, 4), (4, 4, 4)),
+        paddings=(1, 1, 1),
+    ) -> None:
+        super().__init__()
+        # same conditions as UNet:1766-1809
+        if with_conditioning is True and cross_attention_dim is None:
+            raise ValueError("DiffusionModelUNet expects dimension of the cross-attention conditioning (cross_attention_dim) "
+                             "when using with_conditioning.")
+        if cross_attention_dim is not None and with_conditioning is False:
+            raise ValueError("DiffusionModelUNet expects with_conditioning=True when specifying the cross_attention_dim.")
+        if dropout_cattn > 1.0 or dropout_cattn < 0.0:
+            raise ValueError("Dropout cannot be negative or >1.0!")
+        if any((c % norm_num_groups) != 0 for c in num_channels):
+            raise ValueError("DiffusionModelUNet expects all num_channels being multiple of norm_num_groups")
+        if len(num_channels) != len(attention_levels):
+            raise ValueError("DiffusionModelUNet expects num_channels being same size of attention_levels")
+        if isinstance(num_head_channels, int):
+            num_head_channels = _tuple_rep(num_head_channels, len(attention_levels))
+        if len(num_head_channels) != len(attention_levels):
+            raise ValueError("num_head_channels should have the same length as attention_levels.")
+        if isinstance(num_res_blocks, int):
+            num_res_blocks = _tuple_rep(num_res_blocks, len(num_channels))
+        if len(num_res_blocks) != len(num_channels):
+            raise ValueError("`num_res_blocks` should be a single integer or a tuple of integers with the same length as "
+                             "`num_channels`.")
+        if use_flash_attention:
+            raise ValueError("use_flash_attention is True but xformers is not installed.")
+        if with_conditioning or num_class_embeds is not None or resblock_updown:
+            raise NotImplementedError("cross-attention / class-embedding / resblock_updown are not on the HIP path yet "
+                                      "(never enabled by the reference's configs; SURVEY 8f-4)")
+        if spatial_dims not in (2, 3):
+            raise ValueError("spatial_dims must be 2 or 3")
+
+        sd = self.spatial_dims = spatial_dims
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.block_out_channels = ch = tuple(num_channels)
+        self.num_res_blocks = nrb = tuple(num_res_blocks)
+        self.attention_levels = att = tuple(attention_levels)
+        self.num_head_channels = nhc = tuple(num_head_channels)
+        self.with_conditioning = False
+        self.groups, self.eps = norm_num_groups, norm_eps
+        L = len(ch)
+        self._k = [_axis3(kernel_sizes[i], sd, 1) for i in range(L)]
+        self._s = [_axis3(strides[i], sd, 1) for i in range(L)]
+        self._p = [_axis3(paddings[i], sd, 0) for i in range(L)]
+        temb = self.temb_dim = ch[0] * 4
+
+        spec = ParamSpec(self, sd)
+        self._resnets: list[tuple[str, int, int]] = []  # (name, cin, cout) in forward order
+        self._attns: list[str] = []
+
+        def resnet(name, cin, cout):
+            spec.norm(name + ".norm1", cin)
+            spec.conv(name + ".conv1.conv", cin, cout, 3)
+            spec.linear(name + ".time_emb_proj", temb, cout)
+            spec.norm(name + ".norm2", cout)
+            spec.conv(name + ".conv2.conv", cout, cout, 3, zero=True)
+            if cin != cout:
+                spec.conv(name + ".skip_connection.conv", cin, cout, 1)
+            self._resnets.append((name, cin, cout))
+
+        def attn(name, c):
+            spec.attention(name, c)
+            self._attns.append(name)
+
+        spec.conv("conv_in.conv", in_channels, ch[0], kernel_sizes[0])
+        spec.linear("time_embed.0", ch[0], temb)
+        spec.linear("time_embed.2", temb, temb)
+        out_c = ch[0]
+        for i in range(L):
+            in_c, out_c = out_c, ch[i]
+            for j in range(nrb[i]):
+                resnet(f"down_blocks.{i}.resnets.{j}", in_c if j == 0 else out_c, out_c)
+                if att[i]:
+                    attn(f"down_blocks.{i}.attentions.{j}", out_c)
+            if i != L - 1:
+                spec.conv(f"down_blocks.{i}.downsampler.op.conv", out_c, out_c, kernel_sizes[i + 1])
+        resnet("middle_block.resnet_1", ch[-1], ch[-1])
+        attn("middle_block.attention", ch[-1])
+        resnet("middle_block.resnet_2", ch[-1], ch[-1])
+        rch, rnrb, ratt = list(reversed(ch)), list(reversed(nrb)), list(reversed(att))
+        out_c = rch[0]
+        for i in range(L):
+            prev, out_c = out_c, rch[i]
+            in_c = rch[min(i + 1, L - 1)]
+            n = rnrb[i] + 1
+            for j in range(n):
+                skip_c = in_c if j == n - 1 else out_c
+                resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else out_c) + skip_c, out_c)
+                if ratt[i]:
+                    attn(f"up_blocks.{i}.attentions.{j}", out_c)
+            if i != L - 1:
+                spec.conv(f"up_blocks.{i}.upsampler.conv.conv", out_c, out_c, 3)
+        spec.norm("out.0", ch[0])
+        spec.conv("out.2.conv", ch[0], out_channels, 3, zero=True)
+
+        # arena adjacency: one GEMM for every time_emb_proj, one [3C, C] matrix per attention block
+        groups = [[r[0] + ".time_emb_proj.weight" for r in self._resnets], [r[0] + ".time_emb_proj.bias" for r in self._resnets],
+                  [r[0] + ".conv1.conv.bias" for r in self._resnets]]
+        for a in self._attns:
+            groups.append([f"{a}.to_{t}.weight" for t in "qkv"])
+            groups.append([f"{a}.to_{t}.bias" for t in "qkv"])
+        self._init_plumbing(spec, groups)
+        self._temb_off = {}
+        off = 0
+        for name, _, cout in self._resnets:
+            self._temb_off[name] = off
+            off += cout
+        self._temb_total = off
+
+    # ------------------------------------------------------------------------------------------ engine forward
+    def _resnet(self, c, x, name, temb_all, d_temb_all):
+        """ResnetBlock.forward (UNet:674-701) as 2 stats passes + 3 fused convs."""
+        cout = c.p(name + ".conv1.conv.weight").shape[0]
+        off = self._temb_off[name]
+        k3, s1, p1 = (1,) * (3 - self.spatial_dims) + (3,) * self.spatial_dims, (1, 1, 1), (0,) * (3 - self.spatial_dims) + (1,) * self.spatial_dims
+        n1 = E.gn(c, x, name + ".norm1", self.groups, self.eps)
+        h = E.conv(c, x, name + ".conv1.conv", k3, s1, p1, norm=n1, silu=True, addvec=temb_all[:, off:off + cout],
+                   d_addvec=d_temb_all[:, off:off + cout] if d_temb_all is not None else None)
+        n2 = E.gn(c, h, name + ".norm2", self.groups, self.eps)
+        if name + ".skip_connection.conv.weight" in c.arena.offsets:
+            xs = E.conv(c, x, name + ".skip_connection.conv", (1, 1, 1), s1, (0, 0, 0))
+        else:
+            xs = x
+        return E.conv(c, h, name + ".conv2.conv", k3, s1, p1, norm=n2, silu=True, res=xs)
+
+    def _heads(self, ch, nhc):
+        return ch // nhc if nhc is not None else 1
+
+    def _run(self, c: E.Ctx, x_cl, timesteps, need_dx):
+        ch, L, sd = self.block_out_channels, len(self.block_out_channels), self.spatial_dims
+        a = c.arena
+        dev = x_cl.device
+        grad = c.tape is not None
+        # -- time embedding MLP + every time_emb_proj in one GEMM (UNet:1966-1972, 692-695)
+        t0 = ops.timestep_embedding(timesteps, ch[0])
+        e1, bwd1 = E.linear_f32(t0, c.p("time_embed.0.weight"), c.p("time_embed.0.bias"), c.g("time_embed.0.weight"), c.g("time_embed.0.bias"))
+        s1v = ops.silu_f32(e1)
+        emb, bwd2 = E.linear_f32(s1v, c.p("time_embed.2.weight"), c.p("time_embed.2.bias"), c.g("time_embed.2.weight"), c.g("time_embed.2.bias"))
+        se = ops.silu_f32(emb)
+        wn = [r[0] + ".time_emb_proj.weight" for r in self._resnets]
+        bn = [r[0] + ".time_emb_proj.bias" for r in self._resnets]
+        T = self._temb_total
+        temb_all, bwd3 = E.linear_f32(se, a.span(wn).view(T, self.temb_dim), a.span(bn), a.span(wn, a.grad).view(T, self.temb_dim),
+                                      a.span(bn, a.grad))
+        ops.add_f32_(temb_all, a.span([r[0] + ".conv1.conv.bias" for r in self._resnets]))  # fold conv1 biases in
+        d_temb_all = torch.empty_like(temb_all) if grad else None
+        if grad:
+            def bwd_emb():
+                d_se = bwd3(d_temb_all)
+                d_emb = ops.silu_bwd_f32(emb, d_se)
+                d_s1 = bwd2(d_emb)
+                bwd1(ops.silu_bwd_f32(e1, d_s1), need_dx=False)
+
+            c.tape.record(bwd_emb)
+
+        k3 = (1,) * (3 - sd) + (3,) * sd
+        h = E.conv(c, x_cl, "conv_in.conv", self._k[0], self._s[0], self._p[0], need_dx=need_dx)
+        skips = [h]
+        for i in range(L):
+            for j in range(self.num_res_blocks[i]):
+                h = self._resnet(c, h, f"down_blocks.{i}.resnets.{j}", temb_all, d_temb_all)
+                if self.attention_levels[i]:
+                    h = E.attention(c, h, f"down_blocks.{i}.attentions.{j}", self.groups, self.eps, self._heads(ch[i], self.num_head_channels[i]))
+                skips.append(h)
+            if i != L - 1:
+                h = E.conv(c, h, f"down_blocks.{i}.downsampler.op.conv", self._k[i + 1], self._s[i + 1], self._p[i + 1])
+                skips.append(h)
+        h = self._resnet(c, h, "middle_block.resnet_1", temb_all, d_temb_all)
+        h = E.attention(c, h, "middle_block.attention", self.groups, self.eps, self._heads(ch[-1], self.num_head_channels[-1]))
+        h = self._resnet(c, h, "middle_block.resnet_2", temb_all, d_temb_all)
+        rch, rnrb = list(reversed(ch)), list(reversed(self.num_res_blocks))
+        ratt, rnhc = list(reversed(self.attention_levels)), list(reversed(self.num_head_channels))
+        rs, rp = list(reversed(self._s)), list(reversed(self._p))
+        for i in range(L):
+            for j in range(rnrb[i] + 1):
+                h = E.concat(c, h, skips.pop())
+                h = self._resnet(c, h, f"up_blocks.{i}.resnets.{j}", temb_all, d_temb_all)
+                if ratt[i]:
+                    h = E.attention(c, h, f"up_blocks.{i}.attentions.{j}", self.groups, self.eps, self._heads(rch[i], rnhc[i]))
+            if i != L - 1:  # Upsample.forward (UNet:569-588): nearest x stride, then k3 conv with the LEVEL's padding
+                h = E.upsample(c, h, rs[i])
+                h = E.conv(c, h, f"up_blocks.{i}.upsampler.conv.conv", k3, (1, 1, 1), rp[i])
+        no = E.gn(c, h, "out.0", self.groups, self.eps)
+        p1 = (0,) * (3 - sd) + (1,) * sd
+        return E.conv(c, h, "out.2.conv", k3, (1, 1, 1), p1, norm=no, silu=True)
+
+    # ------------------------------------------------------------------------------------------ public forward
+    def forward(self, x, timesteps, context=None, class_labels=None, down_block_additional_residuals=None,
+                mid_block_additional_residual=None):
+        if context is not None:
+            raise ValueError("model should have with_conditioning = True if context is provided")
+        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
+            raise NotImplementedError("ControlNet residual inputs are not on the HIP path yet")
+        if timesteps.ndim != 1:
+            raise ValueError("Timesteps should be a 1d-array")
+        if x.shape[1] != self.in_channels:
+            raise ValueError(f"Input number of channels ({x.shape[1]}) is not equal to expected number of channels ({self.in_channels})")
+        if not x.is_cuda:
+            raise RuntimeError("medical_image_generation_amd runs on MI355X only: move the module and inputs to 'cuda' "
+                               "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
+        timesteps = timesteps.to(device=x.device, dtype=torch.int64)
+
+        def runner(c, xin, need_dx):
+            x_cl = ops.to_channels_last(xin.contiguous().float())
+            y = self._run(c, x_cl, timesteps, need_dx)
+            return (y,), {"x_cl": x_cl}
+
+        grad_enabled = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
+        return _NetFn.apply(self, runner, 1, grad_enabled, x, *self.parameters())

@@ -74,6 +74,8 @@ def test_elementwise_family(ops):
     check(ops.silu_bwd_f32(vd, hd).cpu(), vv.grad, 1e-5, "silu bwd")
     x = rnd(2, 64, 3, 7, 5)
     check(ops.colsum(cl(x)).cpu(), x.sum(dim=(2, 3, 4)), 1e-3, "colsum")
+    x1 = rnd(2, 1, 9, 7, 5)
+    check(ops.colsum(cl(x1)).cpu(), x1.sum(dim=(2, 3, 4)), 1e-3, "colsum ragged")
 
 
 @pytest.mark.parametrize("shape,groups", [((2, 32, 4, 6, 5), 32), ((1, 96, 8, 8, 8), 32), ((2, 64, 1, 16, 16), 16),

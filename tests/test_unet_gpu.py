@@ -1,0 +1,90 @@
+"""End-to-end parity of the HIP DiffusionModelUNet against (a) the golden vectors produced by the reference's own
+model file and (b) the CPU oracle, on identical weights and inputs.
+
+Tolerances (bf16 activations vs an fp32 reference; SURVEY 8c measured torch's own bf16-autocast drift of the
+reference at 2.1e-2 rel-L2 on the prediction and 1.5e-2 on the global gradient):
+  prediction / input gradient : rel-L2 <= 3e-2
+  global parameter gradient   : rel-L2 <= 4e-2
+  per-tensor gradients        : rel-L2 <= 0.15 for tensors that carry signal (norm > 1e-3 of the largest)"""
+import pytest
+import torch
+
+from oracle import cases, nets, synth
+
+pytestmark = pytest.mark.gpu
+S = cases.SEED
+HIP_CASES = ["unet3d", "unet_ldm", "unet_c1"]
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def build(name):
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    c = cases.UNET_CASES[name]
+    ref = nets.DiffusionModelUNet(**c["kwargs"])
+    sd = synth.state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, S)
+    ref.load_state_dict(sd)
+    net = DiffusionModelUNet(**c["kwargs"])
+    assert list(net.state_dict().keys()).sort() == list(sd.keys()).sort()
+    net.load_state_dict(sd)  # strict
+    return c, ref, net.cuda()
+
+
+@pytest.mark.parametrize("name", HIP_CASES)
+def test_unet_forward_backward_matches_reference(golden, name):
+    g, meta = golden(name)
+    c, ref, net = build(name)
+    x = synth.tensor(S, "x", c["shape"])
+    t = torch.tensor(c["timesteps"])
+    gy = synth.tensor(S, "grad_out", g["pred"].shape)
+    xd = x.cuda().requires_grad_(True)
+    pred = net(xd, t.cuda())
+    assert pred.dtype == torch.float32 and pred.shape == g["pred"].shape
+    e_pred = rel_l2(pred.detach().cpu(), g["pred"])
+    pred.backward(gy.cuda())
+    e_dx = rel_l2(xd.grad.cpu(), g["dx"])
+    # oracle gradients (full tensors) for the per-parameter comparison
+    xr = x.clone().requires_grad_(True)
+    ref(xr, t).backward(gy)
+    rg = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+    hg = {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None}
+    assert sorted(hg) == sorted(rg) == meta["grad_names"].split("\n")  # proj_attn.* grad-less on both sides
+    flat_r = torch.cat([rg[n].flatten() for n in sorted(rg)])
+    flat_h = torch.cat([hg[n].flatten() for n in sorted(rg)])
+    e_glob = rel_l2(flat_h, flat_r)
+    big = max(float(v.norm()) for v in rg.values())
+    worst = max(((rel_l2(hg[n], rg[n]), n) for n in rg if float(rg[n].norm()) > 1e-3 * big), default=(0, ""))
+    print(f"\n[{name}] rel-L2: pred {e_pred:.3e}  dx {e_dx:.3e}  grads(global) {e_glob:.3e}  worst tensor {worst[0]:.3e} ({worst[1]})")
+    assert e_pred <= 3e-2 and e_dx <= 3e-2 and e_glob <= 4e-2 and worst[0] <= 0.15
+
+
+def test_unet_pristine_output_is_zero_and_state_dict_roundtrips():
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    c = cases.UNET_CASES["unet3d"]
+    net = DiffusionModelUNet(**c["kwargs"]).cuda()
+    y = net(synth.tensor(S, "x", c["shape"]).cuda(), torch.tensor(c["timesteps"]).cuda())
+    assert float(y.abs().max()) == 0.0  # zero_module'd output conv (UNet:1934)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net2 = DiffusionModelUNet(**c["kwargs"])
+    net2.load_state_dict(sd)
+    assert all(torch.equal(net2.state_dict()[k].cpu(), sd[k].cpu()) for k in sd)
+    ref = nets.DiffusionModelUNet(**c["kwargs"])
+    assert {k: tuple(v.shape) for k, v in ref.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+
+
+def test_unet_errors():
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(3, 1, 1, num_channels=(30, 64), attention_levels=(False, False))
+    with pytest.raises(ValueError):
+        DiffusionModelUNet(3, 1, 1, num_channels=(32, 64), attention_levels=(False,))
+    c = cases.UNET_CASES["unet3d"]
+    net = DiffusionModelUNet(**c["kwargs"]).cuda()
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 2, 8, 8, 8, device="cuda"), torch.zeros(1, dtype=torch.long, device="cuda"))
+    with pytest.raises(ValueError):
+        net(torch.zeros(1, 1, 8, 8, 8, device="cuda"), torch.zeros(1, 1, dtype=torch.long, device="cuda"))
+    with pytest.raises(RuntimeError):
+        net(torch.zeros(1, 1, 8, 8, 8), torch.zeros(1, dtype=torch.long))
