@@ -64,7 +64,7 @@ def cpu_baseline(size=48):
     torch.set_num_threads(os.cpu_count() or 1)
     net = nets.DiffusionModelUNet(**C4)
     for n, p in net.named_parameters():  # un-zero the zero_module'd convs so the backward is not trivially sparse
-        if float(p.abs().max()) == 0:
+        if float(p.detach().abs().max()) == 0:
             torch.nn.init.normal_(p, std=0.02)
     opt = torch.optim.AdamW(net.parameters(), lr=2e-5)
     sched = step.DDPMSchedule()
@@ -102,7 +102,7 @@ def main():
     torch.manual_seed(42)  # identical initial weights on every rank
     net = DiffusionModelUNet(**C4)
     for n, p in net.named_parameters():
-        if float(p.abs().max()) == 0:  # zero_module'd tensors: randomise (otherwise half the backward sees zeros)
+        if float(p.detach().abs().max()) == 0:  # zero_module'd tensors: randomise (otherwise half the backward sees zeros)
             torch.nn.init.normal_(p, std=0.02)
     net = net.to(dev)
     tr = DDPMTrainer(net, lr=2e-5, optimizer="AdamW", max_grad_norm=1.0, device=dev)

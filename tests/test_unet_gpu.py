@@ -65,7 +65,7 @@ def test_unet_pristine_output_is_zero_and_state_dict_roundtrips():
     c = cases.UNET_CASES["unet3d"]
     net = DiffusionModelUNet(**c["kwargs"]).cuda()
     y = net(synth.tensor(S, "x", c["shape"]).cuda(), torch.tensor(c["timesteps"]).cuda())
-    assert float(y.abs().max()) == 0.0  # zero_module'd output conv (UNet:1934)
+    assert float(y.detach().abs().max()) == 0.0  # zero_module'd output conv (UNet:1934)
     sd = {k: v.clone() for k, v in net.state_dict().items()}
     net2 = DiffusionModelUNet(**c["kwargs"])
     net2.load_state_dict(sd)
