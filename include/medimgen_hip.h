@@ -100,6 +100,10 @@ int mi_timestep_embedding(const int64_t* timesteps, float* out, int B, int dim, 
 int mi_silu_f32(const float* x, float* y, int64_t n, hipStream_t stream);
 int mi_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, hipStream_t stream);
 
+/* ---- AutoencoderKL.encode tail: clamp + exp (AEKL:767-769) and backward ------------------------------------------------ */
+int mi_logvar_to_sigma_fwd(const void* logvar, void* sigma, int64_t n, hipStream_t stream);
+int mi_logvar_to_sigma_bwd(const void* dsigma, const void* logvar, const void* sigma, void* dlogvar, int64_t n, hipStream_t stream);
+
 /* ---- train-step glue: scheduler.add_noise (T-LDM:160), F.mse_loss (+backward) (T-LDM:169, T-DDPM:192) ------------------- */
 int mi_qsample(const float* x0, const float* noise, const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod,
                const int64_t* timesteps, void* out, int N, int C, int64_t V, hipStream_t stream);

@@ -50,6 +50,8 @@ _SIGS = {
     "mi_timestep_embedding": [_p, _p, _i, _i, _f, _p],
     "mi_silu_f32": [_p, _p, _l, _p],
     "mi_silu_bwd_f32": [_p, _p, _p, _l, _p],
+    "mi_logvar_to_sigma_fwd": [_p, _p, _l, _p],
+    "mi_logvar_to_sigma_bwd": [_p, _p, _p, _p, _l, _p],
     "mi_qsample": [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p],
     "mi_mse_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _f, _p],
     "mi_sumsq_f32": [_p, _l, _p, _i, _p],

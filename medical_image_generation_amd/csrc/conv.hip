@@ -634,7 +634,9 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   P->strided = P->Q > 1;
   P->Dp = (Di + P->f[0] - 1) / P->f[0]; P->Hp = (Hi + P->f[1] - 1) / P->f[1]; P->Wp = (Wi + P->f[2] - 1) / P->f[2];
   P->KT = k[0] * k[1] * k[2];
-  if (P->strided && (Cin % KC) != 0) { delete P; return MI_ERR_UNSUPPORTED; }  // parity classes must align with 32-channel chunks
+  // parity classes start at q*Cin: 16-byte loads need Cin % 8 == 0.  A class that is not a multiple of 32 channels is
+  // read together with the head of the next class; those extra k-rows meet zero weights (pack masks ci >= Cin).
+  if (P->strided && (Cin % 8) != 0) { delete P; return MI_ERR_UNSUPPORTED; }
   P->ncb_fwd = Cout > 32 ? 2 : 1;
   P->ncb_dg = Cin > 32 ? 2 : 1;
   // forward: loader reads x (or its depth image: dims Dp.., Q*Cin channels); outputs on the (Do,Ho,Wo) grid

@@ -237,6 +237,23 @@ __global__ void __launch_bounds__(256) k_colsum_ragged(const bf16* __restrict__ 
   }
 }
 
+// AutoencoderKL.encode tail (AEKL:767-769): sigma = exp(clamp(logvar, -30, 20) / 2), and its backward
+// (clamp passes the gradient on the closed interval, like aten::clamp)
+__global__ void k_logvar_sigma(const bf16* __restrict__ lv, bf16* __restrict__ sigma, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = fminf(fmaxf(bf2f(lv[i]), -30.f), 20.f);
+    sigma[i] = f2bf(__expf(0.5f * v));
+  }
+}
+__global__ void k_logvar_sigma_bwd(const bf16* __restrict__ dsigma, const bf16* __restrict__ lv, const bf16* __restrict__ sigma,
+                                   bf16* __restrict__ dlv, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = bf2f(lv[i]);
+    bool pass = v >= -30.f && v <= 20.f;
+    dlv[i] = f2bf(pass ? 0.5f * bf2f(dsigma[i]) * bf2f(sigma[i]) : 0.f);
+  }
+}
+
 // y[r][c] += x[r][c] over a [rows][cols] block with row pitches ldx / ldy  (fp32; tiny tensors: biases, embeddings)
 __global__ void k_add_f32_2d(const float* x, int ldx, float* y, int ldy, int rows, int cols) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -388,6 +405,19 @@ int mi_colsum_bf16(const void* x, float* out, int out_stride, int N, int64_t V, 
   int64_t vchunk = 2048;
   int chunks = ceil_div(V, vchunk);
   hipLaunchKernelGGL(k_colsum, dim3(chunks, N), dim3(threads), sizeof(float) * (size_t)rows * C, st, (const bf16*)x, out, out_stride, C, V, vchunk);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_logvar_to_sigma_fwd(const void* logvar, void* sigma, int64_t n, hipStream_t st) {
+  if (n <= 0) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_logvar_sigma, dim3(grid_for(n)), dim3(kThreads), 0, st, (const bf16*)logvar, (bf16*)sigma, n);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_logvar_to_sigma_bwd(const void* dsigma, const void* logvar, const void* sigma, void* dlogvar, int64_t n, hipStream_t st) {
+  if (n <= 0) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_logvar_sigma_bwd, dim3(grid_for(n)), dim3(kThreads), 0, st, (const bf16*)dsigma, (const bf16*)logvar,
+                     (const bf16*)sigma, (bf16*)dlogvar, n);
   MI_CHECK_LAUNCH();
   return 0;
 }

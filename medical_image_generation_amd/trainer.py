@@ -15,6 +15,7 @@ from __future__ import annotations
 import torch
 import torch.distributed as dist
 
+from . import ddp
 from . import engine as E
 from ._lib import call, ptr
 
@@ -56,6 +57,8 @@ class DDPMTrainer:
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         self.bucket_elems = bucket_mb * (1 << 20) // 4
         self.arena = model.arena(self.device)
+        if self.world > 1:
+            ddp.broadcast_parameters(self.arena.data, 0, process_group)
         n = self.arena.n_trainable
         self.exp_avg = torch.zeros(n, dtype=F32, device=self.device)
         self.exp_avg_sq = torch.zeros(n, dtype=F32, device=self.device)
@@ -88,12 +91,8 @@ class DDPMTrainer:
         ctx.tape.grads.clear(), ctx.tape.keep.clear()
 
     def all_reduce_grads(self):
-        if self.world <= 1:
-            return
-        g = self.arena.grad[: self.arena.n_trainable]
-        g.mul_(1.0 / self.world)  # pre-scale: sum of pre-scaled = average, no second pass
-        for o in range(0, g.numel(), self.bucket_elems):
-            dist.all_reduce(g[o:o + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.pg)
+        if self.world > 1:
+            ddp.average_gradients(self.arena.grad, self.arena.n_trainable, self.pg, self.bucket_elems)
 
     def optimizer_step(self):
         a = self.arena

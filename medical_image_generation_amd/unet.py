@@ -136,6 +136,7 @@ class _NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, runner, nouts, grad_enabled, x, *params):
         dev = x.device
+        ctx.set_materialize_grads(False)  # unused outputs (e.g. z_sigma) arrive as None, not as zero tensors
         arena = module.arena(dev)
         c = E.Ctx(arena, module._plans, grad_enabled=grad_enabled)  # (autograd disables grad mode inside forward)
         need_dx = bool(grad_enabled and ctx.needs_input_grad[4])
