@@ -57,11 +57,12 @@ def dominant_kernel_roofline(size, iters=20):
             "avg_launch_us": sec * 1e6}
 
 
-def cpu_baseline(size=48):
+def cpu_baseline(size=32):
     """The oracle (CPU restatement of the reference, fp32) timed on this host: one full train step of the SAME net on a
-    smaller crop (bounded to ~10-30 s)."""
+    smaller crop (bounded to ~10-30 s).  Threads = this job's CPU share (16 per GPU on the pool), not the host's 256."""
     from oracle import nets, step
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     net = nets.DiffusionModelUNet(**C4)
     for n, p in net.named_parameters():  # un-zero the zero_module'd convs so the backward is not trivially sparse
         if float(p.detach().abs().max()) == 0:
@@ -72,7 +73,7 @@ def cpu_baseline(size=48):
     t0 = time.perf_counter()
     step.ddpm_train_step(net, opt, sched, x0, torch.randn_like(x0), torch.tensor([500]))
     dt = time.perf_counter() - t0
-    return {"value": size ** 3 / dt, "unit": "voxels/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": size ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
             "sample": f"1 full train step (fwd+bwd+clip+AdamW) of the C4 U-Net on one {size}^3 crop, fp32, {dt:.1f} s"}
 
 

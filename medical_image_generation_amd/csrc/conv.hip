@@ -62,45 +62,51 @@ struct ConvArgs {
   const float* ss; int ss_C; int pro_silu;  // prologue affine [N][ss_C][2] (channel = src channel % ss_C) or null
   const float* addvec; int addvec_stride;   // fp32 [Cout] (stride 0) or [N] rows of pitch `stride`; null = none
   const bf16* res; int res_cs;
+  int ntiles;
   Geom g;
 };
 
 // ------------------------------------------------------------------------------------------------ halo staging
+// Each thread owns NP 16-byte pieces of the halo image: piece pc = tid + 256*i -> LDS voxel pc >> 2, channel part pc & 3.
+// The voxel's coordinates inside the LDS image do not depend on the tile, so they are decoded ONCE per kernel and kept
+// packed (10 bits per axis); global offsets and validity are rebuilt per tile with a handful of integer ops.
 template <int NP>
 struct Stage {
-  int goff[NP];   // element offset of the voxel in x (without channel), -1 = outside / unused
-  int loff[NP];   // LDS byte offset
-  u32x4 pre[NP];
+  int pk[NP];      // (hd << 20) | (hh << 10) | hw, or -1 for pieces beyond the image
+  u32x4 pre[NP];   // staged data (next image), in flight while the current image is consumed
+  unsigned valid;  // bit i: piece i lies inside the tensor (prologue applies only there: zero padding stays zero)
 };
 
 template <int NP>
-__device__ __forceinline__ void stage_setup(Stage<NP>& s, const ConvArgs& a, int n, int d0, int h0, int w0) {
-  const Geom& g = a.g;
+__device__ __forceinline__ void stage_init(Stage<NP>& s, const Geom& g) {
   const int HVOX = g.HD * g.HH * g.HW;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    int pc = threadIdx.x + 256 * i;
-    int v = pc >> 2, part = pc & 3;
+    int v = (threadIdx.x + 256 * i) >> 2;
     int hdz = v / (g.HH * g.HW);
     int rem = v - hdz * (g.HH * g.HW);
     int hhz = rem / g.HW, hwz = rem - hhz * g.HW;
-    int gd = d0 - g.hd + hdz, gh = h0 - g.hh + hhz, gw = w0 - g.hw + hwz;
-    bool ok = v < HVOX && gd >= 0 && gd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi;
-    s.goff[i] = ok ? (((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) : -1;
-    s.loff[i] = v < HVOX ? hdz * g.slice + hhz * g.row + hwz * VOXB + part * 16 : -1;
+    s.pk[i] = v < HVOX ? ((hdz << 20) | (hhz << 10) | hwz) : -1;
   }
+  s.valid = 0;
 }
 
 template <int NP>
-__device__ __forceinline__ void stage_load(Stage<NP>& s, const ConvArgs& a, int src_c0) {
+__device__ __forceinline__ void stage_load(Stage<NP>& s, const ConvArgs& a, int n, int d0, int h0, int w0, int src_c0) {
+  const Geom& g = a.g;
   const int part = threadIdx.x & 3;
   const int c = src_c0 + part * 8;
   const bool vec = ((a.x_cs & 7) == 0) && (c + 8 <= a.Cin);
+  unsigned valid = 0;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     u32x4 v = {0u, 0u, 0u, 0u};
-    if (s.goff[i] >= 0) {
-      const bf16* p = a.x + (int64_t)s.goff[i] * a.x_cs + c;
+    const int pk = s.pk[i];
+    const int gd = d0 - g.hd + (pk >> 20), gh = h0 - g.hh + ((pk >> 10) & 1023), gw = w0 - g.hw + (pk & 1023);
+    const bool ok = pk >= 0 && gd >= 0 && gd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi;
+    if (ok) {
+      valid |= 1u << i;
+      const bf16* p = a.x + (int64_t)(((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.x_cs + c;
       if (vec) {
         v = *(const u32x4*)p;
       } else {  // ragged channel counts (Cin = 1, 4, ...): element-wise with masking
@@ -112,10 +118,12 @@ __device__ __forceinline__ void stage_load(Stage<NP>& s, const ConvArgs& a, int 
     }
     s.pre[i] = v;
   }
+  s.valid = valid;
 }
 
 template <int NP>
 __device__ __forceinline__ void stage_store(Stage<NP>& s, const ConvArgs& a, int n, int src_c0, char* lds) {
+  const Geom& g = a.g;
   const int part = threadIdx.x & 3;
   float sc[8], sh[8];
   if (a.ss) {
@@ -129,9 +137,10 @@ __device__ __forceinline__ void stage_store(Stage<NP>& s, const ConvArgs& a, int
   }
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    if (s.loff[i] < 0) continue;
+    const int pk = s.pk[i];
+    if (pk < 0) continue;
     u32x4 v = s.pre[i];
-    if (a.ss && s.goff[i] >= 0) {  // zero padding stays zero: the reference pads AFTER norm+activation
+    if (a.ss && ((s.valid >> i) & 1u)) {
       F8 f = unpack8(v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -140,7 +149,7 @@ __device__ __forceinline__ void stage_store(Stage<NP>& s, const ConvArgs& a, int
       }
       v = pack8(f);
     }
-    *(u32x4*)(lds + s.loff[i]) = v;
+    *(u32x4*)(lds + (pk >> 20) * g.slice + ((pk >> 10) & 1023) * g.row + (pk & 1023) * VOXB + part * 16) = v;
   }
 }
 
@@ -161,117 +170,150 @@ __device__ __forceinline__ void block_origin(const Geom& g, int b, int& bd, int&
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad kernel
-template <int NCB, int VB, int NP>
-__global__ void __launch_bounds__(256) k_conv_igemm(ConvArgs a) {
+// Persistent: gridDim.x workgroups (about 2 per CU over all cout groups) walk the tiles.  Workgroups that share
+// `blockIdx.x % 8` are observed to share an XCD (speed only), so each of the 8 residue classes owns a CONTIGUOUS tile
+// range: neighbouring tiles, whose halos overlap, are then served by the same L2.
+__device__ __forceinline__ int first_tile(int ntiles, int& last, int& step) {
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  last = (x + 1) * tpx < ntiles ? (x + 1) * tpx : ntiles;
+  step = nslots;
+  return x * tpx + slot;
+}
+
+template <int NCB, int VB, int NP, int RING, int WPS>
+__global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {  // WPS = 2: two workgroups per CU overlap staging with MFMA
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
   const Geom& g = a.g;
-  int n, d0, h0, w0;
-  tile_origin(g, blockIdx.x, n, d0, h0, w0);
   const int y = blockIdx.y;
+  int tile_last, tile_step;
+  int tile = first_tile(a.ntiles, tile_last, tile_step);
+  if (tile >= tile_last) return;  // whole workgroup, before any barrier
 
-  Stage<NP> st;
-  stage_setup<NP>(st, a, n, d0, h0, w0);
-
-  int bbase[VB];  // LDS byte address of this lane's voxel (tile-relative, halo origin added through the tap offsets)
-  int od[VB], oh[VB], ow[VB];
+  int bbase[VB], bvh[VB], bvw[VB], bvd[VB];  // this lane's voxel inside the tile (LDS byte address / coordinates)
 #pragma unroll
   for (int vb = 0; vb < VB; ++vb) {
     int bd, bh, bw;
     block_origin(g, wave * VB + vb, bd, bh, bw);
-    int vh = bh + (r >> 3), vw = bw + (r & 7);
-    bbase[vb] = bd * g.slice + vh * g.row + vw * VOXB + h * 16;
-    od[vb] = d0 + bd; oh[vb] = h0 + vh; ow[vb] = w0 + vw;
+    bvd[vb] = bd; bvh[vb] = bh + (r >> 3); bvw[vb] = bw + (r & 7);
+    bbase[vb] = bd * g.slice + bvh[vb] * g.row + bvw[vb] * VOXB + h * 16;
   }
-
-  f32x16 acc[VB][NCB];
-#pragma unroll
-  for (int vb = 0; vb < VB; ++vb)
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[vb][cb][e] = 0.f;
-
   const int* hdr = a.hdr + (int64_t)y * a.nchunks * 4;
-  stage_load<NP>(st, a, hdr[2]);
-  for (int ch = 0; ch < a.nchunks; ++ch) {
-    const int tap_begin = hdr[ch * 4 + 0], ntaps = hdr[ch * 4 + 1], src_c0 = hdr[ch * 4 + 2], wfrag = hdr[ch * 4 + 3];
-    __syncthreads();  // every wave is done reading the previous chunk's tile
-    stage_store<NP>(st, a, n, src_c0, lds);
-    __syncthreads();
-    if (ch + 1 < a.nchunks) stage_load<NP>(st, a, hdr[(ch + 1) * 4 + 2]);  // in flight under the MFMAs below
-
-    const u32x4* wp = a.wpk + (int64_t)wfrag * 64 + lane;
-    u32x4 wa[2][NCB], wn[2][NCB];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) wa[ks][cb] = wp[(ks * NCB + cb) * 64];
-    for (int t = 0; t < ntaps; ++t) {
-      if (t + 1 < ntaps) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb) wn[ks][cb] = wp[(((t + 1) * 2 + ks) * NCB + cb) * 64];
-      }
-      const int toff = a.taps[tap_begin + t];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-        for (int vb = 0; vb < VB; ++vb) {
-          bf16x8 fb = *(const bf16x8*)(lds + bbase[vb] + toff + ks * 32);
-#pragma unroll
-          for (int cb = 0; cb < NCB; ++cb)
-            acc[vb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[ks][cb]), fb, acc[vb][cb], 0, 0, 0);
-        }
-      }
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) wa[ks][cb] = wn[ks][cb];
-    }
-  }
-
-  // epilogue: lane holds voxel r of each block, channels co_base + 8*grp + 4*h + (0..3) for grp = 0..3
   const int cls = y / a.ogpq, cls_base = cls * a.outc_q, cls_lim = cls_base + a.outc_q;
+
+  int n, d0, h0, w0;
+  tile_origin(g, tile, n, d0, h0, w0);
+  Stage<NP> st;
+  stage_init<NP>(st, g);
+  stage_load<NP>(st, a, n, d0, h0, w0, hdr[2]);
+  int n_pre = n;  // batch index of the data held in st.pre
+
+  while (true) {
+    f32x16 acc[VB][NCB];
 #pragma unroll
-  for (int vb = 0; vb < VB; ++vb) {
-    if (od[vb] >= a.Do || oh[vb] >= a.Ho || ow[vb] >= a.Wo) continue;
-    const int64_t vox = ((int64_t)(n * a.Do + od[vb]) * a.Ho + oh[vb]) * a.Wo + ow[vb];
+    for (int vb = 0; vb < VB; ++vb)
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
+      for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-      for (int grp = 0; grp < 4; ++grp) {
-        const int co = cls_base + ((y - cls * a.ogpq) * NCB + cb) * 32 + grp * 8 + h * 4;
-        if (co >= cls_lim) continue;
-        float v[4];
+        for (int e = 0; e < 16; ++e) acc[vb][cb][e] = 0.f;
+    const int next_tile = tile + tile_step;
+    int nn = 0, nd0 = 0, nh0 = 0, nw0 = 0;
+
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+      const int tap_begin = hdr[ch * 4 + 0], ntaps = hdr[ch * 4 + 1], src_c0 = hdr[ch * 4 + 2], wfrag = hdr[ch * 4 + 3];
+      // weight ring: the first RING taps' fragments are requested BEFORE the staging phase, which hides their L2 latency
+      const u32x4* wp = a.wpk + (int64_t)wfrag * 64 + lane;
+      u32x4 wa[RING][2][NCB];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = acc[vb][cb][grp * 4 + i];
-        const bool full = (co + 4 <= cls_lim) && ((a.y_cs & 3) == 0);
-        if (a.addvec) {
-          const float* av = a.addvec + (int64_t)n * a.addvec_stride + co;
+      for (int q = 0; q < RING; ++q)
+        if (q < ntaps) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (co + i < cls_lim) v[i] += av[i];
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) wa[q][ks][cb] = wp[((q * 2 + ks) * NCB + cb) * 64];
         }
-        if (a.res) {
-          const bf16* rp = a.res + vox * a.res_cs + co;
+      __syncthreads();  // every wave is done reading the previous tile image
+      stage_store<NP>(st, a, n_pre, src_c0, lds);
+      __syncthreads();
+      // next image (next chunk of this tile, or chunk 0 of this workgroup's next tile): in flight under the MFMAs below
+      if (ch + 1 < a.nchunks) {
+        stage_load<NP>(st, a, n, d0, h0, w0, hdr[(ch + 1) * 4 + 2]);
+      } else if (next_tile < tile_last) {
+        tile_origin(g, next_tile, nn, nd0, nh0, nw0);
+        stage_load<NP>(st, a, nn, nd0, nh0, nw0, hdr[2]);
+        n_pre = nn;
+      }
+      for (int t0 = 0; t0 < ntaps; t0 += RING) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (co + i < cls_lim) v[i] += bf2f(rp[i]);
-        }
-        bf16* yp = a.y + vox * a.y_cs + co;
-        if (full) {
-          u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
-          *(u32x2*)yp = o;
-        } else {
+        for (int q = 0; q < RING; ++q) {
+          const int t = t0 + q;
+          if (t < ntaps) {  // wave-uniform
+            const int toff = a.taps[tap_begin + t];
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (co + i < cls_lim) yp[i] = f2bf(v[i]);
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+              for (int vb = 0; vb < VB; ++vb) {
+                bf16x8 fb = *(const bf16x8*)(lds + bbase[vb] + toff + ks * 32);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+                  acc[vb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[q][ks][cb]), fb, acc[vb][cb], 0, 0, 0);
+              }
+            }
+            if (t + RING < ntaps) {  // refill this slot RING taps ahead
+#pragma unroll
+              for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) wa[q][ks][cb] = wp[(((t + RING) * 2 + ks) * NCB + cb) * 64];
+            }
+          }
         }
       }
     }
+
+    // epilogue: lane holds voxel r of each block, channels co_base + 8*grp + 4*h + (0..3) for grp = 0..3
+#pragma unroll
+    for (int vb = 0; vb < VB; ++vb) {
+      const int od = d0 + bvd[vb], oh = h0 + bvh[vb], ow = w0 + bvw[vb];
+      if (od >= a.Do || oh >= a.Ho || ow >= a.Wo) continue;
+      const int64_t vox = ((int64_t)(n * a.Do + od) * a.Ho + oh) * a.Wo + ow;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+          const int co = cls_base + ((y - cls * a.ogpq) * NCB + cb) * 32 + grp * 8 + h * 4;
+          if (co >= cls_lim) continue;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = acc[vb][cb][grp * 4 + i];
+          const bool full = (co + 4 <= cls_lim) && ((a.y_cs & 3) == 0);
+          if (a.addvec) {
+            const float* av = a.addvec + (int64_t)n * a.addvec_stride + co;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (co + i < cls_lim) v[i] += av[i];
+          }
+          if (a.res) {
+            const bf16* rp = a.res + vox * a.res_cs + co;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (co + i < cls_lim) v[i] += bf2f(rp[i]);
+          }
+          bf16* yp = a.y + vox * a.y_cs + co;
+          if (full) {
+            u32x2 o = {pack2(v[0], v[1]), pack2(v[2], v[3])};
+            *(u32x2*)yp = o;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (co + i < cls_lim) yp[i] = f2bf(v[i]);
+          }
+        }
+      }
+    }
+    if (next_tile >= tile_last) break;
+    tile = next_tile; n = nn; d0 = nd0; h0 = nh0; w0 = nw0;
   }
 }
 
@@ -296,13 +338,57 @@ __device__ __forceinline__ bf16x8 tr_read16(const char* base) {
   return f;
 }
 
+template <int NPY>
+struct StageY {
+  u32x4 pre[NPY];
+};
+
+template <int NPY>
+__device__ __forceinline__ void stagey_load(StageY<NPY>& sy, const WgradArgs& w, int y, int n, int d0, int h0, int w0) {
+  const ConvArgs& a = w.c;
+  const Geom& g = a.g;
+  const int NVOX = g.TD * g.TH * g.TW;
+  const int part = threadIdx.x & 3, co = y * 32 + part * 8;
+#pragma unroll
+  for (int i = 0; i < NPY; ++i) {
+    int v = (threadIdx.x + 256 * i) >> 2;
+    int vd = v / (g.TH * g.TW), rem = v - vd * (g.TH * g.TW);
+    int vh = rem / g.TW, vw = rem - vh * g.TW;
+    int od = d0 + vd, oh = h0 + vh, ow = w0 + vw;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    if (v < NVOX && od < a.Do && oh < a.Ho && ow < a.Wo && co < a.Cout) {
+      const bf16* p = w.dy + ((int64_t)((n * a.Do + od) * a.Ho + oh) * a.Wo + ow) * w.dy_cs + co;
+      if (co + 8 <= a.Cout && (w.dy_cs & 7) == 0) {
+        val = *(const u32x4*)p;
+      } else {
+        F8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f.v[j] = (co + j < a.Cout) ? bf2f(p[j]) : 0.f;
+        val = pack8(f);
+      }
+    }
+    sy.pre[i] = val;
+  }
+}
+
+template <int NPY>
+__device__ __forceinline__ void stagey_store(const StageY<NPY>& sy, const Geom& g, char* ldy) {
+  const int NVOX = g.TD * g.TH * g.TW;
+  const int part = threadIdx.x & 3;
+#pragma unroll
+  for (int i = 0; i < NPY; ++i) {
+    int v = (threadIdx.x + 256 * i) >> 2;
+    if (v < NVOX) *(u32x4*)(ldy + v * VOXB + part * 16) = sy.pre[i];  // dY image: [TD][TH][TW] voxels, pitch VOXB, dense rows
+  }
+}
+
 template <int NP, int NPY, int MAXT>
 __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const ConvArgs& a = w.c;
   const Geom& g = a.g;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  char* ldy = lds + g.lds_bytes;  // dY tile: [TD][TH][TW] voxels x 32 co, pitch VOXB, row pitch TW*VOXB
+  char* ldy = lds + g.lds_bytes;  // dY tile image
   const int pair = blockIdx.x;    // (y, chunk)
   const int y = pair / a.nchunks;
   const int* hdr = a.hdr + (int64_t)pair * 4;
@@ -310,7 +396,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
 
   // transposed-read lane roles: 16-lane group gq -> channel half (gq&1), k half (gq>>1); lane 4q+p -> voxel row q, chan 4p
   const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-  const int kh = gq >> 1;                       // which of the 2 h-rows of the k-step
+  const int kh = gq >> 1;                           // which of the 2 h-rows of the k-step
   const int chan_b = ((gq & 1) * 16 + pp * 4) * 2;  // byte offset of the 4-channel piece inside the voxel
 
   f32x16 acc[MAXT];
@@ -326,47 +412,27 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
     toff[t] = ti < ntaps ? a.taps[tap_begin + ti] : -1;
   }
   const int dyrow = g.TW * VOXB, dyslice = g.TH * dyrow;
-  const int NVOX = g.TD * g.TH * g.TW;
 
-  for (int tile = blockIdx.y; tile < w.ntiles; tile += w.nsplit) {
-    int n, d0, h0, w0;
-    tile_origin(g, tile, n, d0, h0, w0);
-    Stage<NP> st;
-    stage_setup<NP>(st, a, n, d0, h0, w0);
-    stage_load<NP>(st, a, src_c0);
-    // dY tile -> registers
-    u32x4 py[NPY];
-    int pyoff[NPY];
-#pragma unroll
-    for (int i = 0; i < NPY; ++i) {
-      int pc = threadIdx.x + 256 * i;
-      int v = pc >> 2, part = pc & 3;
-      int vd = v / (g.TH * g.TW), rem = v - vd * (g.TH * g.TW);
-      int vh = rem / g.TW, vw = rem - vh * g.TW;
-      int od = d0 + vd, oh = h0 + vh, ow = w0 + vw;
-      int co = y * 32 + part * 8;
-      u32x4 val = {0u, 0u, 0u, 0u};
-      pyoff[i] = v < NVOX ? vd * dyslice + vh * dyrow + vw * VOXB + part * 16 : -1;
-      if (v < NVOX && od < a.Do && oh < a.Ho && ow < a.Wo && co < a.Cout) {
-        const bf16* p = w.dy + ((int64_t)((n * a.Do + od) * a.Ho + oh) * a.Wo + ow) * w.dy_cs + co;
-        if (co + 8 <= a.Cout && (w.dy_cs & 7) == 0) {
-          val = *(const u32x4*)p;
-        } else {
-          F8 f;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) f.v[j] = (co + j < a.Cout) ? bf2f(p[j]) : 0.f;
-          val = pack8(f);
-        }
-      }
-      py[i] = val;
-    }
+  int tile = blockIdx.y;
+  if (tile >= w.ntiles) return;
+  int n, d0, h0, w0;
+  tile_origin(g, tile, n, d0, h0, w0);
+  Stage<NP> st;
+  StageY<NPY> sy;
+  stage_init<NP>(st, g);
+  stage_load<NP>(st, a, n, d0, h0, w0, src_c0);
+  stagey_load<NPY>(sy, w, y, n, d0, h0, w0);
+  while (true) {
     __syncthreads();  // previous tile fully consumed
     stage_store<NP>(st, a, n, src_c0, lds);
-#pragma unroll
-    for (int i = 0; i < NPY; ++i)
-      if (pyoff[i] >= 0) *(u32x4*)(ldy + pyoff[i]) = py[i];
+    stagey_store<NPY>(sy, g, ldy);
     __syncthreads();
-
+    const int next = tile + w.nsplit;
+    if (next < w.ntiles) {  // next tile's loads fly under this tile's MFMAs
+      tile_origin(g, next, n, d0, h0, w0);
+      stage_load<NP>(st, a, n, d0, h0, w0, src_c0);
+      stagey_load<NPY>(sy, w, y, n, d0, h0, w0);
+    }
     // k-steps: 16 voxels = 2 h-rows x 8 w of one slice
     const int ksteps = g.TD * (g.TH / 2) * (g.TW / 8);
     for (int s = 0; s < ksteps; ++s) {
@@ -384,6 +450,8 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
       }
     }
+    if (next >= w.ntiles) break;
+    tile = next;
   }
 
   // partial slab: [tap][co 32][ci 32]; D map: col = lane&31 -> ci, row -> co
@@ -577,15 +645,21 @@ void free_tables(Tables& T) {
   if (T.d_wpk) (void)hipFree(T.d_wpk);
 }
 
-template <int NCB, int VB>
-int launch_igemm(const ConvArgs& a, int ntiles, int ny, hipStream_t st) {
+template <int NCB, int VB, int RING, int WPS>
+int launch_igemm(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   const int hv = a.g.HD * a.g.HH * a.g.HW;
   const int np = (hv * 4 + 255) / 256;
-  dim3 grid(ntiles, ny), blk(256);
+  a.ntiles = ntiles;
+  // persistent grid: ~2 workgroups per CU in total, a multiple of 8 per cout group (one slot set per XCD residue class)
+  int gx = (256 * WPS / ny + 7) / 8 * 8;
+  if (gx < 8) gx = 8;
+  int need = (ntiles + 7) / 8 * 8;
+  if (gx > need) gx = need;
+  dim3 grid(gx, ny), blk(256);
   size_t lds = (size_t)a.g.lds_bytes;
 #define MI_LAUNCH_NP(NPV)                                                                                  \
   do {                                                                                                     \
-    auto kern = k_conv_igemm<NCB, VB, NPV>;                                                                \
+    auto kern = k_conv_igemm<NCB, VB, NPV, RING, WPS>;                                                     \
     static int lds_ok = 0; /* raise the dynamic-LDS limit once per instantiation (not a stream op) */      \
     if ((int)lds > lds_ok) {                                                                               \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -604,9 +678,15 @@ int launch_igemm(const ConvArgs& a, int ntiles, int ny, hipStream_t st) {
   return 0;
 }
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 int launch_igemm_any(const ConvArgs& a, int NCB, int ntiles, int ny, hipStream_t st) {
-  if (NCB == 2) return launch_igemm<2, 2>(a, ntiles, ny, st);
-  return launch_igemm<1, 2>(a, ntiles, ny, st);
+  static const int wps2 = env_int("MI_CONV_NCB2_WPS", 2);  // tuning knob: waves per SIMD of the 64-cout-per-workgroup variant
+  if (NCB == 2) return wps2 == 1 ? launch_igemm<2, 2, 3, 1>(a, ntiles, ny, st) : launch_igemm<2, 2, 2, 2>(a, ntiles, ny, st);
+  return launch_igemm<1, 2, 4, 2>(a, ntiles, ny, st);
 }
 
 }  // namespace
@@ -667,7 +747,7 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   P->wg_split_stride = off;
   P->wg_nitems = (int)(off / 1024);
   int ntiles = N * P->g_wg.tilesD * P->g_wg.tilesH * P->g_wg.tilesW;
-  int nsplit = (1024 + npairs - 1) / npairs;           // aim at ~1024 workgroups
+  int nsplit = (256 + npairs - 1) / npairs;            // one workgroup per CU (the kernel runs one wave per SIMD)
   if (nsplit > ntiles) nsplit = ntiles;
   while (nsplit > 1 && (int64_t)nsplit * off * 4 > (256ll << 20)) nsplit /= 2;  // cap the slab at 256 MiB
   if (nsplit < 1) nsplit = 1;

@@ -207,10 +207,20 @@ __global__ void k_colsum(const bf16* __restrict__ x, float* __restrict__ out, in
 #pragma unroll
   for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
   if (r < rows)
-    for (int64_t v = v0 + r; v < v1; v += rows) {
-      F8 g = unpack8(*(const u32x4*)(x + ((int64_t)n * V + v) * C + cg * 8));
+    for (int64_t v = v0 + r; v < v1; v += 4 * rows) {  // 4 independent 16-byte loads in flight per lane
+      u32x4 raw[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc.v[j] += g.v[j];
+      for (int k = 0; k < 4; ++k) {
+        int64_t vk = v + (int64_t)k * rows;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        raw[k] = vk < v1 ? *(const u32x4*)(x + ((int64_t)n * V + vk) * C + cg * 8) : z;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        F8 g = unpack8(raw[k]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc.v[j] += g.v[j];
+      }
     }
   if (r < rows)
 #pragma unroll

@@ -38,21 +38,32 @@ __global__ void __launch_bounds__(kT) k_gn_partial(const bf16* __restrict__ x, i
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-  if (r < rows)
-    for (int64_t v = v0 + r; v < v1; v += rows) {
-      F8 f = unpack8(*(const u32x4*)(x + ((int64_t)n * V + v) * cstride + cg * 8));
+  if (r < rows) {
+    const bf16* base = x + (int64_t)n * V * cstride + cg * 8;
+    for (int64_t v = v0 + r; v < v1; v += 4 * rows) {  // 4 independent 16-byte loads in flight per lane
+      u32x4 raw[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        s[j] += f.v[j];
-        q[j] += f.v[j] * f.v[j];
+      for (int k = 0; k < 4; ++k) {
+        int64_t vk = v + (int64_t)k * rows;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        raw[k] = vk < v1 ? *(const u32x4*)(base + vk * cstride) : z;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        F8 f = unpack8(raw[k]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s[j] += f.v[j];
+          q[j] += f.v[j] * f.v[j];
+        }
       }
     }
-  if (r < rows)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       sm[(r * C + cg * 8 + j) * 2] = s[j];
       sm[(r * C + cg * 8 + j) * 2 + 1] = q[j];
     }
+  }
   __syncthreads();
   float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * C * 2;
   for (int i = threadIdx.x; i < 2 * C; i += kT) {
@@ -131,15 +142,27 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ 
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
   if (r < rows) {
     load_ss(scale_shift + (int64_t)n * C * 2, cg * 8, sc, sh);
-    for (int64_t v = v0 + r; v < v1; v += rows) {
-      F8 fx = unpack8(*(const u32x4*)(x + ((int64_t)n * V + v) * xcs + cg * 8));
-      F8 fg = unpack8(*(const u32x4*)(g + ((int64_t)n * V + v) * gcs + cg * 8));
+    const bf16* xb = x + (int64_t)n * V * xcs + cg * 8;
+    const bf16* gb = g + (int64_t)n * V * gcs + cg * 8;
+    for (int64_t v = v0 + r; v < v1; v += 4 * rows) {  // 8 independent 16-byte loads in flight per lane
+      u32x4 rx[4], rg[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float du = fg.v[j];
-        if (silu) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
-        s1[j] += du;
-        s2[j] += du * fx.v[j];
+      for (int k = 0; k < 4; ++k) {
+        int64_t vk = v + (int64_t)k * rows;
+        u32x4 z = {0u, 0u, 0u, 0u};
+        rx[k] = vk < v1 ? *(const u32x4*)(xb + vk * xcs) : z;
+        rg[k] = vk < v1 ? *(const u32x4*)(gb + vk * gcs) : z;  // g = 0 beyond the chunk -> contributes nothing
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        F8 fx = unpack8(rx[k]), fg = unpack8(rg[k]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float du = fg.v[j];
+          if (silu) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
+          s1[j] += du;
+          s2[j] += du * fx.v[j];
+        }
       }
     }
 #pragma unroll
@@ -166,25 +189,28 @@ __global__ void k_gn_bwd_finalize(const float* __restrict__ partial, int chunks,
   const int cpg = C / G;
   const float mean = mean_rstd[((int64_t)n * G + g) * 2], rstd = mean_rstd[((int64_t)n * G + g) * 2 + 1];
   double m1 = 0.0, m2 = 0.0;
-  for (int i = threadIdx.x; i < cpg; i += 64) {
+  for (int i = 0; i < cpg; ++i) {  // channels of the group in turn; the 64 lanes split the chunks
     int c = g * cpg + i;
     double s1 = 0.0, s2 = 0.0;
-    for (int ch = 0; ch < chunks; ++ch) {
+    for (int ch = threadIdx.x; ch < chunks; ch += 64) {
       const float* p = partial + (((int64_t)n * chunks + ch) * C + c) * 2;
       s1 += (double)p[0];
       s2 += (double)p[1];
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s1 += __shfl_xor(s1, off, 64);
+      s2 += __shfl_xor(s2, off, 64);
+    }
     double s2hat = (double)rstd * (s2 - (double)mean * s1);  // sum du * xhat
-    sm[2 * i] = (float)s1;
-    sm[2 * i + 1] = (float)s2hat;
-    m1 += (double)gamma[c] * s1;
+    if (threadIdx.x == 0) {
+      sm[2 * i] = (float)s1;
+      sm[2 * i + 1] = (float)s2hat;
+    }
+    m1 += (double)gamma[c] * s1;  // identical in every lane after the butterfly
     m2 += (double)gamma[c] * s2hat;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    m1 += __shfl_xor(m1, off, 64);
-    m2 += __shfl_xor(m2, off, 64);
-  }
+  __syncthreads();
   const double m = (double)V * cpg;
   m1 /= m;
   m2 /= m;
