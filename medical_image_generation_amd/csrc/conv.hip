@@ -44,7 +44,7 @@ struct Geom {           // tile + LDS geometry (host-computed, passed by value)
   int TD, TH, TW;       // output tile (voxels); TD * (TH/4) * (TW/8) == 4 * VB
   int hd, hh, hw;       // halo on each side per axis (0/1)
   int HD, HH, HW;       // LDS tile dims = T + 2*halo
-  int row, slice;       // byte pitches
+  int vox, row, slice;  // byte pitches (voxel: 80 for the b128 fragment reads of fwd/dgrad, 64 for wgrad's transposed reads)
   int lds_bytes;
   int tilesD, tilesH, tilesW;
 };
@@ -63,6 +63,7 @@ struct ConvArgs {
   const float* addvec; int addvec_stride;   // fp32 [Cout] (stride 0) or [N] rows of pitch `stride`; null = none
   const bf16* res; int res_cs;
   int ntiles;
+  unsigned x_bytes, wpk_bytes;  // sizes for the buffer descriptors (both < 4 GiB, checked on the host)
   Geom g;
 };
 
@@ -91,32 +92,44 @@ __device__ __forceinline__ void stage_init(Stage<NP>& s, const Geom& g) {
   s.valid = 0;
 }
 
+// Wave-uniform buffer descriptor (raw, no stride): 32-bit per-lane byte offsets, hardware range check (an offset beyond
+// num_records loads zeros -- which is exactly the conv's zero padding), scalar soffset for wave-uniform displacements.
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+
 template <int NP>
 __device__ __forceinline__ void stage_load(Stage<NP>& s, const ConvArgs& a, int n, int d0, int h0, int w0, int src_c0) {
   const Geom& g = a.g;
   const int part = threadIdx.x & 3;
   const int c = src_c0 + part * 8;
   const bool vec = ((a.x_cs & 7) == 0) && (c + 8 <= a.Cin);
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
   unsigned valid = 0;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    u32x4 v = {0u, 0u, 0u, 0u};
     const int pk = s.pk[i];
     const int gd = d0 - g.hd + (pk >> 20), gh = h0 - g.hh + ((pk >> 10) & 1023), gw = w0 - g.hw + (pk & 1023);
     const bool ok = pk >= 0 && gd >= 0 && gd < a.Di && gh >= 0 && gh < a.Hi && gw >= 0 && gw < a.Wi;
-    if (ok) {
-      valid |= 1u << i;
-      const bf16* p = a.x + (int64_t)(((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.x_cs + c;
-      if (vec) {
-        v = *(const u32x4*)p;
-      } else {  // ragged channel counts (Cin = 1, 4, ...): element-wise with masking
+    valid |= ok ? (1u << i) : 0u;
+    const unsigned off = ok ? (unsigned)((((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.x_cs + c) * 2u : 0xffffffffu;
+    if (vec) {
+      s.pre[i] = buf_load16(rx, off, 0);  // out-of-range offset -> zeros
+    } else {  // ragged channel counts (Cin = 1, 4, ...): element-wise with masking
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const bf16* p = a.x + (off >> 1);
         F8 f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) f.v[j] = (c + j < a.Cin) ? bf2f(p[j]) : 0.f;
         v = pack8(f);
       }
+      s.pre[i] = v;
     }
-    s.pre[i] = v;
   }
   s.valid = valid;
 }
@@ -149,7 +162,7 @@ __device__ __forceinline__ void stage_store(Stage<NP>& s, const ConvArgs& a, int
       }
       v = pack8(f);
     }
-    *(u32x4*)(lds + (pk >> 20) * g.slice + ((pk >> 10) & 1023) * g.row + (pk & 1023) * VOXB + part * 16) = v;
+    *(u32x4*)(lds + (pk >> 20) * g.slice + ((pk >> 10) & 1023) * g.row + (pk & 1023) * g.vox + part * 16) = v;
   }
 }
 
@@ -181,8 +194,72 @@ __device__ __forceinline__ int first_tile(int ntiles, int& last, int& step) {
   return x * tpx + slot;
 }
 
-template <int NCB, int VB, int NP, int RING, int WPS>
-__global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {  // WPS = 2: two workgroups per CU overlap staging with MFMA
+// LDS reads the compiler may not move or wait for: issue-early / wait-late is placed by hand (cdna guide 5.7, form (ii):
+// the wait statement names every destination "+v", and a sched_barrier keeps the MFMAs on their side of it).
+template <int OFF>
+__device__ __forceinline__ void lds_read16_async(u32x4& dst, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int VB>
+__device__ __forceinline__ void lds_wait_frags(u32x4 (&f)[2][VB]) {
+  if constexpr (VB == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]));
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0]), "+v"(f[1][0]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int OFF>
+__device__ __forceinline__ void lds_read16_async(u32x4& dst, unsigned addr);
+template <int VB>
+__device__ __forceinline__ void lds_wait_frags(u32x4 (&f)[2][VB]);
+
+constexpr int F27_ROW = 896, F27_SLICE = 8960;  // LDS pitches of the 4x8x8 (+1 halo) tile every k3-s1 3-D conv uses
+template <int T, int FLIP>
+constexpr int f27_off() {  // byte offset of tap T's window (mirrored for the data gradient)
+  constexpr int U = FLIP ? 26 - T : T;
+  return (U / 9) * F27_SLICE + ((U / 3) % 3) * F27_ROW + (U % 3) * VOXB;
+}
+
+template <int T, int FLIP, int VB>
+__device__ __forceinline__ void f27_issue(u32x4 (&f)[2][VB], const unsigned (&baddr)[VB]) {
+#pragma unroll
+  for (int vb = 0; vb < VB; ++vb) {
+    lds_read16_async<f27_off<T, FLIP>()>(f[0][vb], baddr[vb]);
+    lds_read16_async<f27_off<T, FLIP>() + 32>(f[1][vb], baddr[vb]);
+  }
+}
+// taps T..26, fully unrolled by template recursion so every LDS offset is an immediate
+template <int T, int NCB, int VB, int RING, int FLIP>
+__device__ __forceinline__ void f27_taps(f32x16 (&acc)[VB][NCB], u32x4 (&wa)[RING][2][NCB], u32x4 (&fb)[2][2][VB],
+                                         const unsigned (&baddr)[VB], __amdgpu_buffer_rsrc_t rw, unsigned wsoff) {
+  if constexpr (T < 27) {
+    constexpr int q = T % RING, cur = T & 1;
+    if constexpr (T + 1 < 27) f27_issue<T + 1, FLIP, VB>(fb[cur ^ 1], baddr);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          acc[vb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[q][ks][cb]),
+                                                                __builtin_bit_cast(bf16x8, fb[cur][ks][vb]), acc[vb][cb], 0, 0, 0);
+    if constexpr (T + RING < 27) {
+      const unsigned wlane = (threadIdx.x & 63) * 16u;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) wa[q][ks][cb] = buf_load16(rw, wlane, wsoff + (((T + RING) * 2 + ks) * NCB + cb) * 1024u);
+    }
+    if constexpr (T + 1 < 27) lds_wait_frags<VB>(fb[cur ^ 1]);
+    f27_taps<T + 1, NCB, VB, RING, FLIP>(acc, wa, fb, baddr, rw, wsoff);
+  }
+}
+
+template <int NCB, int VB, int NP, int RING, int WPS, int MODE>  // MODE 0: table-driven taps, 1: k3-s1 forward, 2: k3-s1 dgrad
+__global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {
+  constexpr bool FULL27 = MODE != 0;
+  constexpr int FLIP = MODE == 2;  // WPS = 2: two workgroups per CU overlap staging with MFMA
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h = lane >> 5;
@@ -198,7 +275,7 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {  // WPS =
     int bd, bh, bw;
     block_origin(g, wave * VB + vb, bd, bh, bw);
     bvd[vb] = bd; bvh[vb] = bh + (r >> 3); bvw[vb] = bw + (r & 7);
-    bbase[vb] = bd * g.slice + bvh[vb] * g.row + bvw[vb] * VOXB + h * 16;
+    bbase[vb] = bd * g.slice + bvh[vb] * g.row + bvw[vb] * g.vox + h * 16;
   }
   const int* hdr = a.hdr + (int64_t)y * a.nchunks * 4;
   const int cls = y / a.ogpq, cls_base = cls * a.outc_q, cls_lim = cls_base + a.outc_q;
@@ -224,7 +301,9 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {  // WPS =
     for (int ch = 0; ch < a.nchunks; ++ch) {
       const int tap_begin = hdr[ch * 4 + 0], ntaps = hdr[ch * 4 + 1], src_c0 = hdr[ch * 4 + 2], wfrag = hdr[ch * 4 + 3];
       // weight ring: the first RING taps' fragments are requested BEFORE the staging phase, which hides their L2 latency
-      const u32x4* wp = a.wpk + (int64_t)wfrag * 64 + lane;
+      const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpk, a.wpk_bytes);
+      const unsigned wsoff = (unsigned)wfrag * 1024u;  // scalar byte offset of this chunk's first fragment
+      const unsigned wlane = lane * 16u;
       u32x4 wa[RING][2][NCB];
 #pragma unroll
       for (int q = 0; q < RING; ++q)
@@ -232,7 +311,7 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {  // WPS =
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) wa[q][ks][cb] = wp[((q * 2 + ks) * NCB + cb) * 64];
+            for (int cb = 0; cb < NCB; ++cb) wa[q][ks][cb] = buf_load16(rw, wlane, wsoff + ((q * 2 + ks) * NCB + cb) * 1024u);
         }
       __syncthreads();  // every wave is done reading the previous tile image
       stage_store<NP>(st, a, n_pre, src_c0, lds);
@@ -245,6 +324,25 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {  // WPS =
         stage_load<NP>(st, a, nn, nd0, nh0, nw0, hdr[2]);
         n_pre = nn;
       }
+      if constexpr (FULL27) {
+        // k3 s1 in all three axes: the 27 taps are a compile-time loop nest (offsets = i*slice + j*row + k*VOXB, mirrored
+        // for the data gradient), so the whole chunk is straight-line code the scheduler can software-pipeline.
+        // B fragments are double-buffered by hand: tap t+1's LDS reads are issued before tap t's MFMAs and waited for after
+        // them (left to itself hipcc puts each ds_read right in front of its consumer: one LDS round trip per MFMA).  The
+        // tap offsets are immediates, so one address register per voxel block serves all 27 taps.
+        typedef __attribute__((address_space(3))) char lds_char;
+        const unsigned lds0 = (unsigned)(size_t)(lds_char*)lds;
+        unsigned baddr[VB];
+#pragma unroll
+        for (int vb = 0; vb < VB; ++vb) {
+          baddr[vb] = lds0 + bbase[vb];
+          asm volatile("" : "+v"(baddr[vb]));  // keep it ONE register: no per-tap address hoisting
+        }
+        u32x4 fb[2][2][VB];
+        f27_issue<0, FLIP, VB>(fb[0], baddr);
+        lds_wait_frags<VB>(fb[0]);
+        f27_taps<0, NCB, VB, RING, FLIP>(acc, wa, fb, baddr, rw, wsoff);
+      } else {
       for (int t0 = 0; t0 < ntaps; t0 += RING) {
 #pragma unroll
         for (int q = 0; q < RING; ++q) {
@@ -265,10 +363,12 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {  // WPS =
 #pragma unroll
               for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) wa[q][ks][cb] = wp[(((t + RING) * 2 + ks) * NCB + cb) * 64];
+                for (int cb = 0; cb < NCB; ++cb)
+                  wa[q][ks][cb] = buf_load16(rw, wlane, wsoff + (((t + RING) * 2 + ks) * NCB + cb) * 1024u);
             }
           }
         }
+      }
       }
     }
 
@@ -327,15 +427,41 @@ struct WgradArgs {
   int ntiles, nsplit;
 };
 
-__device__ __forceinline__ bf16x8 tr_read16(const char* base) {
-  // two ds_read_b64_tr_b16: 4 voxels x 16 channels each, delivered channel-per-lane (see header comment)
-  typedef __attribute__((address_space(3))) bf16x4 lds_v4;
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(base));
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(base + 4 * VOXB));
-  bf16x8 f;
-  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-  return f;
+// ds_read_b64_tr_b16 (4 voxels x 16 channels delivered channel-per-lane) issued through asm so that a whole k-step's
+// reads can be put in flight before the previous k-step's MFMAs; waited for by wg_wait (cdna guide 5.7 form (ii)).
+__device__ __forceinline__ void tr_read_async(u32x2& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(dst) : "v"(addr));
+}
+template <int MAXT>
+struct WgFrags {
+  u32x2 a[2];
+  u32x2 b[MAXT][2];
+};
+template <int MAXT>
+__device__ __forceinline__ void wg_issue(WgFrags<MAXT>& f, unsigned ya, unsigned xa, const int (&toff)[MAXT], int vox4) {
+  tr_read_async(f.a[0], ya);
+  tr_read_async(f.a[1], ya + vox4);
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    tr_read_async(f.b[t][0], xa + toff[t]);
+    tr_read_async(f.b[t][1], xa + toff[t] + vox4);
+  }
+}
+template <int MAXT>
+__device__ __forceinline__ void wg_wait(WgFrags<MAXT>& f) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.a[0]), "+v"(f.a[1]));
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) asm volatile("" : "+v"(f.b[t][0]), "+v"(f.b[t][1]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <int MAXT>
+__device__ __forceinline__ void wg_mfma(f32x16 (&acc)[MAXT], const WgFrags<MAXT>& f) {
+  u32x4 ra = {f.a[0][0], f.a[0][1], f.a[1][0], f.a[1][1]};
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    u32x4 rb = {f.b[t][0][0], f.b[t][0][1], f.b[t][1][0], f.b[t][1][1]};
+    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra), __builtin_bit_cast(bf16x8, rb), acc[t], 0, 0, 0);
+  }
 }
 
 template <int NPY>
@@ -378,7 +504,7 @@ __device__ __forceinline__ void stagey_store(const StageY<NPY>& sy, const Geom& 
 #pragma unroll
   for (int i = 0; i < NPY; ++i) {
     int v = (threadIdx.x + 256 * i) >> 2;
-    if (v < NVOX) *(u32x4*)(ldy + v * VOXB + part * 16) = sy.pre[i];  // dY image: [TD][TH][TW] voxels, pitch VOXB, dense rows
+    if (v < NVOX) *(u32x4*)(ldy + v * g.vox + part * 16) = sy.pre[i];  // dY image: [TD][TH][TW] voxels, dense
   }
 }
 
@@ -389,6 +515,8 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
   const Geom& g = a.g;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   char* ldy = lds + g.lds_bytes;  // dY tile image
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned lds0 = (unsigned)(size_t)(lds_char*)lds, ldy0 = lds0 + g.lds_bytes;
   const int pair = blockIdx.x;    // (y, chunk)
   const int y = pair / a.nchunks;
   const int* hdr = a.hdr + (int64_t)pair * 4;
@@ -405,13 +533,15 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+  // Slots beyond this wave's share of the taps read tap 0's (valid) window into an accumulator that is never stored:
+  // no branch inside the k loop, so all LDS reads of a k-step can be issued ahead of its MFMAs.
   int toff[MAXT];
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
     int ti = wave + 4 * t;
-    toff[t] = ti < ntaps ? a.taps[tap_begin + ti] : -1;
+    toff[t] = a.taps[tap_begin + (ti < ntaps ? ti : 0)];
   }
-  const int dyrow = g.TW * VOXB, dyslice = g.TH * dyrow;
+  const int dyrow = g.TW * g.vox, dyslice = g.TH * dyrow;
 
   int tile = blockIdx.y;
   if (tile >= w.ntiles) return;
@@ -433,21 +563,30 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
       stage_load<NP>(st, a, n, d0, h0, w0, src_c0);
       stagey_load<NPY>(sy, w, y, n, d0, h0, w0);
     }
-    // k-steps: 16 voxels = 2 h-rows x 8 w of one slice
-    const int ksteps = g.TD * (g.TH / 2) * (g.TW / 8);
-    for (int s = 0; s < ksteps; ++s) {
-      int sw = (s % (g.TW / 8)) * 8;
-      int sh = ((s / (g.TW / 8)) % (g.TH / 2)) * 2;
-      int sd = s / ((g.TW / 8) * (g.TH / 2));
-      // lane address for voxel (sd, sh + kh, sw + q) [+4 voxels for the second read], channel piece chan_b
-      const char* ya = ldy + sd * dyslice + (sh + kh) * dyrow + (sw + q) * VOXB + chan_b;
-      bf16x8 fa = tr_read16(ya);
-      const char* xa = lds + sd * g.slice + (sh + kh) * g.row + (sw + q) * VOXB + chan_b;
-#pragma unroll
-      for (int t = 0; t < MAXT; ++t) {
-        if (toff[t] < 0) continue;  // wave-uniform
-        bf16x8 fb = tr_read16(xa + toff[t]);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[t], 0, 0, 0);
+    // k-steps: 16 voxels = 2 h-rows x 8 w of one slice, walked with incremental counters (no divisions); the reads of
+    // k-step s+1 are in flight under the MFMAs of k-step s (two statically named fragment sets, loop unrolled in pairs).
+    {
+      int sd = 0, sh = 0, sw = 0;
+      auto addr_y = [&]() { return ldy0 + sd * dyslice + (sh + kh) * dyrow + (sw + q) * g.vox + chan_b; };
+      auto addr_x = [&]() { return lds0 + sd * g.slice + (sh + kh) * g.row + (sw + q) * g.vox + chan_b; };
+      auto advance = [&]() {
+        sw += 8;
+        if (sw >= g.TW) { sw = 0; sh += 2; if (sh >= g.TH) { sh = 0; ++sd; } }
+      };
+      const int ksteps = g.TD * (g.TH / 2) * (g.TW / 8);  // even (checked on the host)
+      const int vox4 = 4 * g.vox;
+      WgFrags<MAXT> fA, fB;
+      wg_issue<MAXT>(fA, addr_y(), addr_x(), toff, vox4);
+      wg_wait<MAXT>(fA);
+      for (int s = 0; s < ksteps; s += 2) {
+        advance();
+        wg_issue<MAXT>(fB, addr_y(), addr_x(), toff, vox4);
+        wg_mfma<MAXT>(acc, fA);
+        wg_wait<MAXT>(fB);
+        advance();
+        if (s + 2 < ksteps) wg_issue<MAXT>(fA, addr_y(), addr_x(), toff, vox4);
+        wg_mfma<MAXT>(acc, fB);
+        if (s + 2 < ksteps) wg_wait<MAXT>(fA);
       }
     }
     if (next >= w.ntiles) break;
@@ -516,17 +655,20 @@ struct Tables {
 
 int rup(int v, int m) { return (v + m - 1) / m * m; }
 
-Geom make_geom(int VB, int Do, int Ho, int Wo, const int halo[3], int N) {
+Geom make_geom(int VB, int Do, int Ho, int Wo, const int halo[3], int N, int vox = VOXB) {
   Geom g;
+  g.vox = vox;
   // tile = 4*VB blocks of 4x8 voxels (VB blocks per wave); single-slice volumes (2-D nets) put all blocks in one slice
   if (Do == 1) { g.TD = 1; g.TH = 16; g.TW = 8 * VB; }
   else { g.TD = 2 * VB; g.TH = 8; g.TW = 8; }
   g.hd = halo[0]; g.hh = halo[1]; g.hw = halo[2];
   g.HD = g.TD + 2 * g.hd; g.HH = g.TH + 2 * g.hh; g.HW = g.TW + 2 * g.hw;
-  int row = g.HW * VOXB;
+  int row = g.HW * vox;
   int rr = rup(row, 256) + 128;           // == 128 (mod 256), >= row  (may overshoot by < 256)
   if (rr - 256 >= row) rr -= 256;
-  g.row = rr;
+  // 64-byte voxels (wgrad): a transposed read covers 4 consecutive voxels = 256 contiguous bytes = every bank once,
+  // whatever the alignment -> dense rows
+  g.row = vox == VOXB ? rr : row;
   g.slice = g.HH * g.row;
   g.lds_bytes = g.HD * g.slice;
   g.tilesD = (Do + g.TD - 1) / g.TD; g.tilesH = (Ho + g.TH - 1) / g.TH; g.tilesW = (Wo + g.TW - 1) / g.TW;
@@ -552,6 +694,7 @@ struct mi_conv_plan {
   bf16* d_xs = nullptr;   // space-to-depth image of x (strided convs)
   bf16* d_dxs = nullptr;  // depth image of dx
   bool strided = false;
+  bool full27 = false;  // k3 s1 p1 on all three axes: compile-time tap nest
 };
 
 namespace {
@@ -573,7 +716,7 @@ bool axis_combos_dgrad(int k, int s, int p, std::vector<AxisCombo>& out) {
 }
 
 int tap_lds_off(const Geom& g, int dd, int dh, int dw) {
-  return (dd + g.hd) * g.slice + (dh + g.hh) * g.row + (dw + g.hw) * VOXB;
+  return (dd + g.hd) * g.slice + (dh + g.hh) * g.row + (dw + g.hw) * g.vox;
 }
 
 // Build tables for:  out channels = OutC (grouped in blocks of 32*NCB; group -> (qo, co-block) when out is a depth image),
@@ -645,8 +788,9 @@ void free_tables(Tables& T) {
   if (T.d_wpk) (void)hipFree(T.d_wpk);
 }
 
-template <int NCB, int VB, int RING, int WPS>
+template <int NCB, int VB, int RING, int WPS, int MODE>
 int launch_igemm(ConvArgs a, int ntiles, int ny, hipStream_t st) {
+  if (MODE != 0 && (a.g.row != F27_ROW || a.g.slice != F27_SLICE || a.g.TD != 4 || a.g.TH != 8 || a.g.TW != 8)) return MI_ERR_BAD_ARG;
   const int hv = a.g.HD * a.g.HH * a.g.HW;
   const int np = (hv * 4 + 255) / 256;
   a.ntiles = ntiles;
@@ -659,7 +803,7 @@ int launch_igemm(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   size_t lds = (size_t)a.g.lds_bytes;
 #define MI_LAUNCH_NP(NPV)                                                                                  \
   do {                                                                                                     \
-    auto kern = k_conv_igemm<NCB, VB, NPV, RING, WPS>;                                                     \
+    auto kern = k_conv_igemm<NCB, VB, NPV, RING, WPS, MODE>;                                               \
     static int lds_ok = 0; /* raise the dynamic-LDS limit once per instantiation (not a stream op) */      \
     if ((int)lds > lds_ok) {                                                                               \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -668,11 +812,16 @@ int launch_igemm(ConvArgs a, int ntiles, int ny, hipStream_t st) {
     }                                                                                                      \
     hipLaunchKernelGGL(kern, grid, blk, lds, st, a);                                                       \
   } while (0)
-  if (np <= 4) MI_LAUNCH_NP(4);
-  else if (np <= 6) MI_LAUNCH_NP(6);
-  else if (np <= 10) MI_LAUNCH_NP(10);
-  else if (np <= 16) MI_LAUNCH_NP(16);
-  else return MI_ERR_BAD_ARG;
+  if constexpr (MODE != 0) {  // fixed 4x8x8 (+halo) geometry: 2400 pieces -> 10 per thread
+    if (np != 10) return MI_ERR_BAD_ARG;
+    MI_LAUNCH_NP(10);
+  } else {
+    if (np <= 4) MI_LAUNCH_NP(4);
+    else if (np <= 6) MI_LAUNCH_NP(6);
+    else if (np <= 10) MI_LAUNCH_NP(10);
+    else if (np <= 16) MI_LAUNCH_NP(16);
+    else return MI_ERR_BAD_ARG;
+  }
 #undef MI_LAUNCH_NP
   MI_CHECK_LAUNCH();
   return 0;
@@ -683,10 +832,18 @@ int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-int launch_igemm_any(const ConvArgs& a, int NCB, int ntiles, int ny, hipStream_t st) {
-  static const int wps2 = env_int("MI_CONV_NCB2_WPS", 2);  // tuning knob: waves per SIMD of the 64-cout-per-workgroup variant
-  if (NCB == 2) return wps2 == 1 ? launch_igemm<2, 2, 3, 1>(a, ntiles, ny, st) : launch_igemm<2, 2, 2, 2>(a, ntiles, ny, st);
-  return launch_igemm<1, 2, 4, 2>(a, ntiles, ny, st);
+int launch_igemm_any(const ConvArgs& a, int NCB, int mode, int ntiles, int ny, hipStream_t st) {
+  static const int wps2 = env_int("MI_CONV_NCB2_WPS", 2);  // tuning knob for the 64-cout-per-workgroup variant
+  if (mode == 1) {
+    if (NCB == 2) return wps2 == 1 ? launch_igemm<2, 2, 3, 1, 1>(a, ntiles, ny, st) : launch_igemm<2, 2, 2, 2, 1>(a, ntiles, ny, st);
+    return launch_igemm<1, 2, 3, 2, 1>(a, ntiles, ny, st);
+  }
+  if (mode == 2) {
+    if (NCB == 2) return wps2 == 1 ? launch_igemm<2, 2, 3, 1, 2>(a, ntiles, ny, st) : launch_igemm<2, 2, 2, 2, 2>(a, ntiles, ny, st);
+    return launch_igemm<1, 2, 3, 2, 2>(a, ntiles, ny, st);
+  }
+  if (NCB == 2) return launch_igemm<2, 2, 2, 2, 0>(a, ntiles, ny, st);
+  return launch_igemm<1, 2, 4, 2, 0>(a, ntiles, ny, st);
 }
 
 }  // namespace
@@ -714,6 +871,8 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   P->strided = P->Q > 1;
   P->Dp = (Di + P->f[0] - 1) / P->f[0]; P->Hp = (Hi + P->f[1] - 1) / P->f[1]; P->Wp = (Wi + P->f[2] - 1) / P->f[2];
   P->KT = k[0] * k[1] * k[2];
+  P->full27 = true;
+  for (int a = 0; a < 3; ++a) P->full27 = P->full27 && k[a] == 3 && s[a] == 1 && p[a] == 1;
   // parity classes start at q*Cin: 16-byte loads need Cin % 8 == 0.  A class that is not a multiple of 32 channels is
   // read together with the head of the next class; those extra k-rows meet zero weights (pack masks ci >= Cin).
   if (P->strided && (Cin % 8) != 0) { delete P; return MI_ERR_UNSUPPORTED; }
@@ -726,7 +885,7 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   P->g_dg = make_geom(2, P->Dp, P->Hp, P->Wp, halo_d, N);
   build_tables(P->dg, P->g_dg, P->ncb_dg, cdg, P->f, P->k, false, Cout, Cin, true);
   // wgrad: forward geometry, 32-cout groups
-  P->g_wg = P->g_fwd;
+  P->g_wg = make_geom(2, P->Do, P->Ho, P->Wo, halo_f, N, 64);
   build_tables(P->wg, P->g_wg, 1, cf, P->f, P->k, true, Cin, Cout, false);
   int e;
   if ((e = upload_tables(P->fwd, true)) || (e = upload_tables(P->dg, true)) || (e = upload_tables(P->wg, false))) { mi_conv_plan_destroy(P); return e; }
@@ -815,7 +974,13 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
   a.res = (const bf16*)res; a.res_cs = res_cs;
   a.g = P->g_fwd;
   int ntiles = P->N * a.g.tilesD * a.g.tilesH * a.g.tilesW;
-  return launch_igemm_any(a, P->ncb_fwd, ntiles, P->fwd.ny, st);
+  a.wpk_bytes = (unsigned)P->fwd.nfrags * 1024u;
+  {
+    int64_t xb = (int64_t)a.N * a.Di * a.Hi * a.Wi * a.x_cs * 2;
+    if (xb >= (1ll << 32)) return MI_ERR_UNSUPPORTED;
+    a.x_bytes = (unsigned)xb;
+  }
+  return launch_igemm_any(a, P->ncb_fwd, P->full27 ? 1 : 0, ntiles, P->fwd.ny, st);
 }
 
 int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_cs, hipStream_t st) {
@@ -835,7 +1000,13 @@ int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_c
   a.wpk = P->dg.d_wpk; a.hdr = P->dg.d_hdr; a.taps = P->dg.d_taps; a.nchunks = P->dg.nchunks;
   a.g = P->g_dg;
   int ntiles = P->N * a.g.tilesD * a.g.tilesH * a.g.tilesW;
-  int e = launch_igemm_any(a, P->ncb_dg, ntiles, P->dg.ny, st);
+  a.wpk_bytes = (unsigned)P->dg.nfrags * 1024u;
+  {
+    int64_t xb = (int64_t)a.N * a.Di * a.Hi * a.Wi * a.x_cs * 2;
+    if (xb >= (1ll << 32)) return MI_ERR_UNSUPPORTED;
+    a.x_bytes = (unsigned)xb;
+  }
+  int e = launch_igemm_any(a, P->ncb_dg, P->full27 ? 2 : 0, ntiles, P->dg.ny, st);
   if (e) return e;
   if (P->strided) return mi_depth_to_space(P->d_dxs, dx, P->N, P->Di, P->Hi, P->Wi, P->Cin, P->f[0], P->f[1], P->f[2], st);
   return 0;
@@ -863,6 +1034,11 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   a.Cout = P->Cout; a.Do = P->Do; a.Ho = P->Ho; a.Wo = P->Wo;
   a.hdr = P->wg.d_hdr; a.taps = P->wg.d_taps; a.nchunks = P->wg.nchunks;
   a.ss = scale_shift; a.ss_C = P->Cin; a.pro_silu = silu;
+  {
+    int64_t xb = (int64_t)a.N * a.Di * a.Hi * a.Wi * a.x_cs * 2;
+    if (xb >= (1ll << 32)) return MI_ERR_UNSUPPORTED;
+    a.x_bytes = (unsigned)xb;
+  }
   a.g = P->g_wg;
   w.dy = (const bf16*)dy; w.dy_cs = dy_cs;
   w.part = P->d_part; w.pair_off = P->d_pair_off; w.split_stride = P->wg_split_stride;
@@ -872,12 +1048,21 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   const int np = (hv * 4 + 255) / 256;
   const int nvox = a.g.TD * a.g.TH * a.g.TW;
   const int npy = (nvox * 4 + 255) / 256;
-  size_t lds = (size_t)a.g.lds_bytes + (size_t)nvox * VOXB;
+  size_t lds = (size_t)a.g.lds_bytes + (size_t)nvox * a.g.vox;
   dim3 grid(P->wg.ny * P->wg.nchunks, w.nsplit), blk(256);
+  if ((a.g.TD * (a.g.TH / 2) * (a.g.TW / 8)) % 2) return MI_ERR_BAD_ARG;  // the k loop is unrolled in pairs
   if (npy > 4 || np > 16) return MI_ERR_BAD_ARG;
+  int max_taps = 0;
+  for (size_t i = 1; i < P->wg.hdr.size(); i += 4) max_taps = P->wg.hdr[i] > max_taps ? P->wg.hdr[i] : max_taps;
 #define MI_LAUNCH_WG(NPV)                                                                                          \
   do {                                                                                                             \
-    auto kern = k_conv_wgrad<NPV, 4, 7>;                                                                           \
+    if (max_taps <= 4) MI_LAUNCH_WG_T(NPV, 1);                                                                     \
+    else if (max_taps <= 12) MI_LAUNCH_WG_T(NPV, 3);                                                               \
+    else MI_LAUNCH_WG_T(NPV, 7);                                                                                   \
+  } while (0)
+#define MI_LAUNCH_WG_T(NPV, MT)                                                                                    \
+  do {                                                                                                             \
+    auto kern = k_conv_wgrad<NPV, 4, MT>;                                                                          \
     static int lds_ok = 0;                                                                                         \
     if ((int)lds > lds_ok) {                                                                                       \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -891,6 +1076,7 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   else if (np <= 10) MI_LAUNCH_WG(10);
   else MI_LAUNCH_WG(16);
 #undef MI_LAUNCH_WG
+#undef MI_LAUNCH_WG_T
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((int)(((int64_t)P->wg_nitems * 1024 + 255) / 256)), dim3(256), 0, st, P->d_part, P->wg_split_stride,
                      P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT);
   MI_CHECK_LAUNCH();

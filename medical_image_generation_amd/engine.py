@@ -19,6 +19,13 @@ from ._lib import call, ptr
 
 BF16, F32 = torch.bfloat16, torch.float32
 
+# GroupNorm(+SiLU) in front of a conv: either fused into the conv's staging (no activated tensor in HBM, but the
+# transcendental is evaluated on 2.3x halo-inflated data in forward AND in wgrad) or one standalone apply pass whose bf16
+# output both kernels read.  Measured on MI355X (tools/bench_conv.py): fused costs +85 us per 32-channel 128^3 conv per
+# use, the standalone pass 54 us once -> standalone is the default; MI_FUSE_PROLOGUE=1 selects the fused path.
+import os as _os
+FUSE_PROLOGUE = _os.environ.get("MI_FUSE_PROLOGUE", "0") == "1"
+
 
 # --------------------------------------------------------------------------------------------- parameters
 class ParamArena:
@@ -140,7 +147,11 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
         plan.pack(wt)  # [Cout, Cin, (kd,) kh, kw] contiguous: same memory layout for 2-D and 3-D nets
         ctx.packed.add(key)
     av = addvec if addvec is not None else ctx.p(name + ".bias")
-    y = plan.fwd(x, norm, silu, addvec=av, res=res)
+    if norm is not None and not FUSE_PROLOGUE:
+        xin, pn, ps = ops.gn_apply(x, norm, silu), None, False
+    else:
+        xin, pn, ps = x, norm, silu
+    y = plan.fwd(xin, pn, ps, addvec=av, res=res)
     ctx.count(2 * y.numel() * cin * math.prod(kernel), dgrad=need_dx)
     if ctx.tape is not None:
         tape = ctx.tape
@@ -150,7 +161,7 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
             if dy is None:
                 return
             gw = ctx.g(name + ".weight")
-            plan.wgrad(x, dy, gw, norm, silu)
+            plan.wgrad(xin, dy, gw, pn, ps)
             gb = ctx.g(name + ".bias")
             if d_addvec is not None:  # per-sample sums -> temb gradient; bias gradient = their sum over n
                 ops.colsum(dy, out=d_addvec, accumulate=False)
