@@ -76,14 +76,17 @@ int mi_conv_fwd(mi_conv_plan* plan, const void* x, int x_cstride, const float* s
                 int addvec_stride, const void* res, int res_cstride, void* y, int y_cstride, hipStream_t stream);
 /* dx = conv_transpose(dy)  (gradient w.r.t. the ACTIVATED input) */
 int mi_conv_dgrad(mi_conv_plan* plan, const void* dy, int dy_cstride, void* dx, int dx_cstride, hipStream_t stream);
-/* dweight += x_act^T * dy   (fp32, torch layout; x_act recomputed from x with the same fused prologue) */
+/* dweight += x_act^T * dy   (fp32, torch layout; x_act recomputed from x with the same fused prologue).
+ * dy_colsum (optional, fp32, ACCUMULATED): dy_colsum[n*stride + co] += sum over voxels of dy -- the bias / time-embedding
+ * gradient, produced from the dY tiles the kernel already holds in LDS */
 int mi_conv_wgrad(mi_conv_plan* plan, const void* x, int x_cstride, const float* scale_shift, int silu, const void* dy, int dy_cstride,
-                  float* dweight, hipStream_t stream);
+                  float* dweight, float* dy_colsum, int dy_colsum_stride, hipStream_t stream);
 /* out[n*out_stride + c] (+)= sum_v x[n][v][c]  (bias / time-embedding gradients) */
 int mi_colsum_bf16(const void* x, float* out, int out_stride, int N, int64_t V, int C, int accumulate, hipStream_t stream);
 /* tiny fp32 helpers for bias / embedding vectors: y[r][c] += x[r][c];  out[c] (+)= sum_r in[r][c] */
 int mi_add_f32_2d(const float* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t stream);
 int mi_sum_rows_f32(const float* in, int ld, int rows, int cols, float* out, int accumulate, hipStream_t stream);
+int mi_zero_f32_2d(float* x, int ld, int rows, int cols, hipStream_t stream);
 
 /* ---- aten::mm/addmm/bmm/baddbmm + _softmax (+backward): nn.Linear (UNet:379-381,646,1832-1834), AttentionBlock._attention
  *      (UNet:406-416, AEKL:271-281).  C[z] = alpha*A[z]*B[z]^T (+bias[n]) (+R[z]);  z -> (z/Z2, z%Z2) two-level batch strides -- */

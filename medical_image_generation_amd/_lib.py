@@ -39,10 +39,11 @@ _SIGS = {
     "mi_conv_pack_weights": [_p, _p, _p],
     "mi_conv_fwd": [_p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
     "mi_conv_dgrad": [_p, _p, _i, _p, _i, _p],
-    "mi_conv_wgrad": [_p, _p, _i, _p, _i, _p, _i, _p, _p],
+    "mi_conv_wgrad": [_p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p],
     "mi_colsum_bf16": [_p, _p, _i, _i, _l, _i, _i, _p],
     "mi_add_f32_2d": [_p, _i, _p, _i, _i, _i, _p],
     "mi_sum_rows_f32": [_p, _i, _i, _i, _p, _i, _p],
+    "mi_zero_f32_2d": [_p, _i, _i, _i, _p],
     "mi_gemm_nt_bf16": [_p, _i, _l, _l, _p, _i, _l, _l, _p, _i, _l, _l, _p, _p, _i, _l, _l, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "mi_transpose_bf16": [_p, _i, _l, _l, _p, _i, _l, _l, _i, _i, _i, _i, _p],
     "mi_softmax_fwd": [_p, _p, _l, _i, _p],

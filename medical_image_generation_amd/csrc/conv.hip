@@ -425,6 +425,9 @@ struct WgradArgs {
   const int* pair_off;  // [npairs] float offset of the pair's slab inside one split's partial
   int64_t split_stride; // floats per split
   int ntiles, nsplit;
+  int dbg;              // ablation knob (MI_WGRAD_DBG): 1 = stage only the first tile, 2 = skip the MFMA loop
+  float* colsum;        // optional: colsum[n * colsum_stride + co] += sum over voxels of dy (bias / time-embedding gradient)
+  int colsum_stride;
 };
 
 // ds_read_b64_tr_b16 (4 voxels x 16 channels delivered channel-per-lane) issued through asm so that a whole k-step's
@@ -547,22 +550,45 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
   if (tile >= w.ntiles) return;
   int n, d0, h0, w0;
   tile_origin(g, tile, n, d0, h0, w0);
+  // fused bias-gradient: thread -> (channel cs_co, voxel phase cs_grp); flushed with one atomic per (image, thread)
+  const bool do_colsum = w.colsum != nullptr && (pair % a.nchunks) == 0;
+  const int cs_co = threadIdx.x & 31, cs_grp = threadIdx.x >> 5;
+  float cs_acc = 0.f;
+  int cs_n = -1, n_img = n;
   Stage<NP> st;
   StageY<NPY> sy;
   stage_init<NP>(st, g);
   stage_load<NP>(st, a, n, d0, h0, w0, src_c0);
   stagey_load<NPY>(sy, w, y, n, d0, h0, w0);
+  bool first = true;
   while (true) {
     __syncthreads();  // previous tile fully consumed
-    stage_store<NP>(st, a, n, src_c0, lds);
-    stagey_store<NPY>(sy, g, ldy);
+    if (w.dbg != 1 || first) {
+      stage_store<NP>(st, a, n, src_c0, lds);
+      stagey_store<NPY>(sy, g, ldy);
+    }
     __syncthreads();
+    if (do_colsum) {  // this workgroup owns the first cin chunk of its cout block: it also reduces dY over voxels
+      if (n_img != cs_n) {  // image changed (tiles are visited in increasing order): flush
+        if (cs_n >= 0 && y * 32 + cs_co < a.Cout) atomicAdd(w.colsum + (int64_t)cs_n * w.colsum_stride + y * 32 + cs_co, cs_acc);
+        cs_acc = 0.f;
+        cs_n = n_img;
+      }
+      const int nvox = g.TD * g.TH * g.TW;
+      const char* col = ldy + cs_co * 2;
+      for (int v = cs_grp; v < nvox; v += 8) cs_acc += bf2f(*(const bf16*)(col + v * g.vox));
+    }
     const int next = tile + w.nsplit;
     if (next < w.ntiles) {  // next tile's loads fly under this tile's MFMAs
       tile_origin(g, next, n, d0, h0, w0);
-      stage_load<NP>(st, a, n, d0, h0, w0, src_c0);
-      stagey_load<NPY>(sy, w, y, n, d0, h0, w0);
+      n_img = n;  // image of the tile that will be in LDS at the next iteration
+      if (w.dbg != 1) {
+        stage_load<NP>(st, a, n, d0, h0, w0, src_c0);
+        stagey_load<NPY>(sy, w, y, n, d0, h0, w0);
+      }
     }
+    first = false;
+    if (w.dbg != 2)
     // k-steps: 16 voxels = 2 h-rows x 8 w of one slice, walked with incremental counters (no divisions); the reads of
     // k-step s+1 are in flight under the MFMAs of k-step s (two statically named fragment sets, loop unrolled in pairs).
     {
@@ -592,6 +618,9 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
     if (next >= w.ntiles) break;
     tile = next;
   }
+
+  if (do_colsum && cs_n >= 0 && y * 32 + cs_co < a.Cout)
+    atomicAdd(w.colsum + (int64_t)cs_n * w.colsum_stride + y * 32 + cs_co, cs_acc);
 
   // partial slab: [tap][co 32][ci 32]; D map: col = lane&31 -> ci, row -> co
   float* out = w.part + (int64_t)blockIdx.y * w.split_stride + w.pair_off[pair];
@@ -1014,7 +1043,7 @@ int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_c
 
 // dw (fp32, torch layout [Cout][Cin][kd][kh][kw]) += wgrad;  x side takes the same fused prologue as the forward
 int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const void* dy, int dy_cs, float* dw,
-                  hipStream_t st) {
+                  float* dy_colsum, int dy_colsum_stride, hipStream_t st) {
   if (!P || !x || !dy || !dw || x_cs < P->Cin || dy_cs < P->Cout) return MI_ERR_BAD_ARG;
   WgradArgs w;
   memset(&w, 0, sizeof(w));
@@ -1044,6 +1073,10 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   w.part = P->d_part; w.pair_off = P->d_pair_off; w.split_stride = P->wg_split_stride;
   w.ntiles = P->N * a.g.tilesD * a.g.tilesH * a.g.tilesW;
   w.nsplit = P->wg_nsplit;
+  static const int dbg = env_int("MI_WGRAD_DBG", 0);
+  w.dbg = dbg;
+  w.colsum = dy_colsum; w.colsum_stride = dy_colsum_stride;
+  if (dy_colsum && dy_colsum_stride < P->Cout) return MI_ERR_BAD_ARG;
   const int hv = a.g.HD * a.g.HH * a.g.HW;
   const int np = (hv * 4 + 255) / 256;
   const int nvox = a.g.TD * a.g.TH * a.g.TW;

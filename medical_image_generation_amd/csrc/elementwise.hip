@@ -437,6 +437,11 @@ int mi_add_f32_2d(const float* x, int ldx, float* y, int ldy, int rows, int cols
   MI_CHECK_LAUNCH();
   return 0;
 }
+int mi_zero_f32_2d(float* x, int ld, int rows, int cols, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || ld < cols) return MI_ERR_BAD_ARG;
+  hipError_t e = hipMemset2DAsync(x, sizeof(float) * (size_t)ld, 0, sizeof(float) * (size_t)cols, (size_t)rows, st);
+  return (int)e;
+}
 int mi_sum_rows_f32(const float* in, int ld, int rows, int cols, float* out, int accumulate, hipStream_t st) {
   if (rows <= 0 || cols <= 0) return MI_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_sum_rows_f32, dim3(ceil_div(cols, 256)), dim3(256), 0, st, in, ld, rows, cols, out, accumulate);

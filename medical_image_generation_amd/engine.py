@@ -161,13 +161,13 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
             if dy is None:
                 return
             gw = ctx.g(name + ".weight")
-            plan.wgrad(xin, dy, gw, pn, ps)
             gb = ctx.g(name + ".bias")
-            if d_addvec is not None:  # per-sample sums -> temb gradient; bias gradient = their sum over n
-                ops.colsum(dy, out=d_addvec, accumulate=False)
-                ops.sum_rows_f32(d_addvec, gb, accumulate=True)
-            else:
-                ops.colsum(dy, out=gb.view(1, cout), accumulate=True, merge_batch=True)
+            # per-image column sums of dy come out of the wgrad kernel (it holds every dY tile in LDS anyway):
+            # they are the time-embedding gradient; the bias gradient is their sum over the batch
+            cs = d_addvec if d_addvec is not None else torch.empty((n, cout), dtype=F32, device=dy.device)
+            ops.zero_f32_2d_(cs)
+            plan.wgrad(xin, dy, gw, pn, ps, colsum=cs)
+            ops.sum_rows_f32(cs, gb, accumulate=True)
             if res is not None:
                 tape.put(res, dy)
             if need_dx:

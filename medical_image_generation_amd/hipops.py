@@ -185,10 +185,15 @@ class ConvPlan:
         call("mi_conv_dgrad", self.handle, ptr(dy), _cs(dy), ptr(dx), self.cin)
         return dx
 
-    def wgrad(self, x, dy, dweight_f32, st: GNStats | None = None, silu=False):
+    def wgrad(self, x, dy, dweight_f32, st: GNStats | None = None, silu=False, colsum=None):
+        """dweight += wgrad; colsum (optional fp32 [N, Cout] view, row pitch honoured) += per-image column sums of dy."""
         assert dweight_f32.dtype == F32 and dweight_f32.is_contiguous()
+        cs_stride = 0
+        if colsum is not None:
+            assert colsum.dtype == F32 and colsum.shape == (self.n, self.cout) and colsum.stride(1) == 1
+            cs_stride = colsum.stride(0)
         call("mi_conv_wgrad", self.handle, ptr(x), _cs(x), ptr(st.scale_shift) if st is not None else None, int(silu), ptr(dy), _cs(dy),
-             ptr(dweight_f32))
+             ptr(dweight_f32), ptr(colsum), cs_stride)
 
 
 def colsum(x, out=None, accumulate=False, merge_batch=False):
@@ -216,6 +221,13 @@ def add_f32_(y, x):
     assert y2.stride(1) == 1
     call("mi_add_f32_2d", ptr(xp), ldx, ptr(y2), y2.stride(0), y2.shape[0], y2.shape[1])
     return y
+
+
+def zero_f32_2d_(x):
+    """zero a small fp32 matrix that may be a column slice of a wider one (hipMemset2DAsync, no torch kernel)."""
+    assert x.dim() == 2 and x.stride(1) == 1
+    call("mi_zero_f32_2d", ptr(x), x.stride(0), x.shape[0], x.shape[1])
+    return x
 
 
 def sum_rows_f32(x, out, accumulate=True):

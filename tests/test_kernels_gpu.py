@@ -169,8 +169,10 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     check(cf(plan.fwd(xc, addvec=bias.to(dev))), y.detach(), 1e-2, "conv fwd")
     check(cf(plan.dgrad(gc)), xr.grad, 1e-2, "conv dgrad")
     dw = torch.ones_like(w).to(dev)  # wgrad accumulates
-    plan.wgrad(xc, gc, dw)
+    cs = torch.ones((n, cout), device=dev)
+    plan.wgrad(xc, gc, dw, colsum=cs)
     check(dw.cpu() - 1, wr.grad, 1e-2, "conv wgrad")
+    check(cs.cpu() - 1, g.sum(dim=(2, 3, 4)), 1e-2, "fused dy column sums (bias / temb gradient)")
 
 
 def test_conv_fused_prologue_epilogue(ops):
