@@ -78,12 +78,12 @@ struct Stage {
   unsigned valid;  // bit i: piece i lies inside the tensor (prologue applies only there: zero padding stays zero)
 };
 
-template <int NP>
+template <int NP, int NT = 256>
 __device__ __forceinline__ void stage_init(Stage<NP>& s, const Geom& g) {
   const int HVOX = g.HD * g.HH * g.HW;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
-    int v = (threadIdx.x + 256 * i) >> 2;
+    int v = (threadIdx.x + NT * i) >> 2;
     int hdz = v / (g.HH * g.HW);
     int rem = v - hdz * (g.HH * g.HW);
     int hhz = rem / g.HW, hwz = rem - hhz * g.HW;
@@ -472,7 +472,7 @@ struct StageY {
   u32x4 pre[NPY];
 };
 
-template <int NPY>
+template <int NPY, int NT = 256>
 __device__ __forceinline__ void stagey_load(StageY<NPY>& sy, const WgradArgs& w, int y, int n, int d0, int h0, int w0) {
   const ConvArgs& a = w.c;
   const Geom& g = a.g;
@@ -480,7 +480,7 @@ __device__ __forceinline__ void stagey_load(StageY<NPY>& sy, const WgradArgs& w,
   const int part = threadIdx.x & 3, co = y * 32 + part * 8;
 #pragma unroll
   for (int i = 0; i < NPY; ++i) {
-    int v = (threadIdx.x + 256 * i) >> 2;
+    int v = (threadIdx.x + NT * i) >> 2;
     int vd = v / (g.TH * g.TW), rem = v - vd * (g.TH * g.TW);
     int vh = rem / g.TW, vw = rem - vh * g.TW;
     int od = d0 + vd, oh = h0 + vh, ow = w0 + vw;
@@ -500,19 +500,97 @@ __device__ __forceinline__ void stagey_load(StageY<NPY>& sy, const WgradArgs& w,
   }
 }
 
-template <int NPY>
+template <int NPY, int NT = 256>
 __device__ __forceinline__ void stagey_store(const StageY<NPY>& sy, const Geom& g, char* ldy) {
   const int NVOX = g.TD * g.TH * g.TW;
   const int part = threadIdx.x & 3;
 #pragma unroll
   for (int i = 0; i < NPY; ++i) {
-    int v = (threadIdx.x + 256 * i) >> 2;
+    int v = (threadIdx.x + NT * i) >> 2;
     if (v < NVOX) *(u32x4*)(ldy + v * g.vox + part * 16) = sy.pre[i];  // dY image: [TD][TH][TW] voxels, dense
   }
 }
 
-template <int NP, int NPY, int MAXT>
-__global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
+// One pass over the tile's 16 k-steps (16 voxels = 2 h-rows x 8 w of one slice) for a wave that owns NTAP taps.
+// Reads of k-step s+1 are in flight under the MFMAs of k-step s (two statically named fragment sets, loop unrolled in pairs).
+template <int NTAP>
+__device__ __forceinline__ void wg_tile(f32x16 (&acc)[NTAP], const int (&toff)[NTAP], const Geom& g, unsigned lds0, unsigned ldy0,
+                                        int kh, int q, int chan_b, int dyrow, int dyslice, int dbg) {
+  int sd = 0, sh = 0, sw = 0;
+  auto addr_y = [&]() { return ldy0 + sd * dyslice + (sh + kh) * dyrow + (sw + q) * g.vox + chan_b; };
+  auto addr_x = [&]() { return lds0 + sd * g.slice + (sh + kh) * g.row + (sw + q) * g.vox + chan_b; };
+  auto advance = [&]() {
+    sw += 8;
+    if (sw >= g.TW) { sw = 0; sh += 2; if (sh >= g.TH) { sh = 0; ++sd; } }
+  };
+  const int ksteps = g.TD * (g.TH / 2) * (g.TW / 8);  // even (checked on the host)
+  const int vox4 = 4 * g.vox;
+  WgFrags<NTAP> fA, fB;
+  wg_issue<NTAP>(fA, addr_y(), addr_x(), toff, vox4);
+  wg_issue<NTAP>(fB, addr_y(), addr_x(), toff, vox4);
+  wg_wait<NTAP>(fA);
+  wg_wait<NTAP>(fB);
+  for (int s = 0; s < ksteps; s += 2) {
+    advance();
+    if (dbg != 4) wg_issue<NTAP>(fB, addr_y(), addr_x(), toff, vox4);
+    if (dbg != 3) wg_mfma<NTAP>(acc, fA);
+    if (dbg != 4) wg_wait<NTAP>(fB);
+    advance();
+    if (s + 2 < ksteps && dbg != 4) wg_issue<NTAP>(fA, addr_y(), addr_x(), toff, vox4);
+    if (dbg != 3) wg_mfma<NTAP>(acc, fB);
+    if (s + 2 < ksteps && dbg != 4) wg_wait<NTAP>(fA);
+  }
+}
+
+// 3-D k3 convs always use the 4x8x8 (+1 halo) tile with 64-byte voxels: row 640, slice 6400 for the x image, 512 / 4096
+// for the dY image.  Every k-step / half-row offset is then a ds_read immediate; one address register per tap, set once.
+constexpr int WG3_XROW = 640, WG3_XSLICE = 6400, WG3_YROW = 512, WG3_YSLICE = 4096;
+template <int OFF>
+__device__ __forceinline__ void tr_read_async_i(u32x2& dst, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int S, int NTAP>
+__device__ __forceinline__ void wg3_issue(WgFrags<NTAP>& f, unsigned ybase, const unsigned (&xbase)[NTAP]) {
+  constexpr int OY = (S >> 2) * WG3_YSLICE + (S & 3) * 2 * WG3_YROW;
+  constexpr int OX = (S >> 2) * WG3_XSLICE + (S & 3) * 2 * WG3_XROW;
+  tr_read_async_i<OY>(f.a[0], ybase);
+  tr_read_async_i<OY + 256>(f.a[1], ybase);
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) {
+    tr_read_async_i<OX>(f.b[t][0], xbase[t]);
+    tr_read_async_i<OX + 256>(f.b[t][1], xbase[t]);
+  }
+}
+template <int S, int NTAP>
+__device__ __forceinline__ void wg3_steps(f32x16 (&acc)[NTAP], WgFrags<NTAP>& fcur, WgFrags<NTAP>& fnext, unsigned ybase,
+                                          const unsigned (&xbase)[NTAP]) {
+  if constexpr (S < 16) {
+    if constexpr (S + 1 < 16) wg3_issue<S + 1, NTAP>(fnext, ybase, xbase);
+    wg_mfma<NTAP>(acc, fcur);
+    if constexpr (S + 1 < 16) wg_wait<NTAP>(fnext);
+    wg3_steps<S + 1, NTAP>(acc, fnext, fcur, ybase, xbase);
+  }
+}
+template <int NTAP>
+__device__ __forceinline__ void wg3_tile(f32x16 (&acc)[NTAP], const int (&toff)[NTAP], unsigned lds0, unsigned ldy0, int kh, int q,
+                                         int chan_b) {
+  const unsigned lane_y = ldy0 + kh * WG3_YROW + q * 64 + chan_b;
+  unsigned xbase[NTAP];
+#pragma unroll
+  for (int t = 0; t < NTAP; ++t) xbase[t] = lds0 + kh * WG3_XROW + q * 64 + chan_b + toff[t];
+  WgFrags<NTAP> fA, fB;
+  wg3_issue<0, NTAP>(fA, lane_y, xbase);
+  wg_wait<NTAP>(fA);
+  wg3_steps<0, NTAP>(acc, fA, fB, lane_y, xbase);
+}
+
+// 512 threads = 8 waves = 2 per SIMD: ds_read_b64_tr_b16 is issue-bound for a lone wave (an 8-byte LDS read needs several
+// waves per SIMD to approach its rate), so two waves alternate LDS reads and MFMAs on every SIMD.  The pair's taps are dealt
+// round-robin over the 8 waves (27 taps -> 4,4,4,3,3,3,3,3: every SIMD gets 7 or 6); each wave keeps its taps' 32x32
+// accumulators for the whole tile range of the workgroup.
+template <int NP, int NPY, bool GEO3D>
+__global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
+  constexpr int NT = 512, MAXT = 4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const ConvArgs& a = w.c;
   const Geom& g = a.g;
@@ -535,14 +613,13 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
   for (int t = 0; t < MAXT; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
-
-  // Slots beyond this wave's share of the taps read tap 0's (valid) window into an accumulator that is never stored:
-  // no branch inside the k loop, so all LDS reads of a k-step can be issued ahead of its MFMAs.
   int toff[MAXT];
+  int nt = 0;  // taps of this wave: wave, wave + 8, ...
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
-    int ti = wave + 4 * t;
+    int ti = wave + 8 * t;
     toff[t] = a.taps[tap_begin + (ti < ntaps ? ti : 0)];
+    nt += ti < ntaps ? 1 : 0;
   }
   const int dyrow = g.TW * g.vox, dyslice = g.TH * dyrow;
 
@@ -557,15 +634,15 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
   int cs_n = -1, n_img = n;
   Stage<NP> st;
   StageY<NPY> sy;
-  stage_init<NP>(st, g);
+  stage_init<NP, NT>(st, g);
   stage_load<NP>(st, a, n, d0, h0, w0, src_c0);
-  stagey_load<NPY>(sy, w, y, n, d0, h0, w0);
+  stagey_load<NPY, NT>(sy, w, y, n, d0, h0, w0);
   bool first = true;
   while (true) {
     __syncthreads();  // previous tile fully consumed
-    if (w.dbg != 1 || first) {
+    if ((w.dbg != 1 && w.dbg < 3) || first) {
       stage_store<NP>(st, a, n, src_c0, lds);
-      stagey_store<NPY>(sy, g, ldy);
+      stagey_store<NPY, NT>(sy, g, ldy);
     }
     __syncthreads();
     if (do_colsum) {  // this workgroup owns the first cin chunk of its cout block: it also reduces dY over voxels
@@ -576,43 +653,33 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
       }
       const int nvox = g.TD * g.TH * g.TW;
       const char* col = ldy + cs_co * 2;
-      for (int v = cs_grp; v < nvox; v += 8) cs_acc += bf2f(*(const bf16*)(col + v * g.vox));
+      for (int v = cs_grp; v < nvox; v += NT / 32) cs_acc += bf2f(*(const bf16*)(col + v * g.vox));
     }
     const int next = tile + w.nsplit;
     if (next < w.ntiles) {  // next tile's loads fly under this tile's MFMAs
       tile_origin(g, next, n, d0, h0, w0);
       n_img = n;  // image of the tile that will be in LDS at the next iteration
-      if (w.dbg != 1) {
+      if (w.dbg != 1 && w.dbg < 3) {
         stage_load<NP>(st, a, n, d0, h0, w0, src_c0);
-        stagey_load<NPY>(sy, w, y, n, d0, h0, w0);
+        stagey_load<NPY, NT>(sy, w, y, n, d0, h0, w0);
       }
     }
     first = false;
-    if (w.dbg != 2)
-    // k-steps: 16 voxels = 2 h-rows x 8 w of one slice, walked with incremental counters (no divisions); the reads of
-    // k-step s+1 are in flight under the MFMAs of k-step s (two statically named fragment sets, loop unrolled in pairs).
-    {
-      int sd = 0, sh = 0, sw = 0;
-      auto addr_y = [&]() { return ldy0 + sd * dyslice + (sh + kh) * dyrow + (sw + q) * g.vox + chan_b; };
-      auto addr_x = [&]() { return lds0 + sd * g.slice + (sh + kh) * g.row + (sw + q) * g.vox + chan_b; };
-      auto advance = [&]() {
-        sw += 8;
-        if (sw >= g.TW) { sw = 0; sh += 2; if (sh >= g.TH) { sh = 0; ++sd; } }
-      };
-      const int ksteps = g.TD * (g.TH / 2) * (g.TW / 8);  // even (checked on the host)
-      const int vox4 = 4 * g.vox;
-      WgFrags<MAXT> fA, fB;
-      wg_issue<MAXT>(fA, addr_y(), addr_x(), toff, vox4);
-      wg_wait<MAXT>(fA);
-      for (int s = 0; s < ksteps; s += 2) {
-        advance();
-        wg_issue<MAXT>(fB, addr_y(), addr_x(), toff, vox4);
-        wg_mfma<MAXT>(acc, fA);
-        wg_wait<MAXT>(fB);
-        advance();
-        if (s + 2 < ksteps) wg_issue<MAXT>(fA, addr_y(), addr_x(), toff, vox4);
-        wg_mfma<MAXT>(acc, fB);
-        if (s + 2 < ksteps) wg_wait<MAXT>(fA);
+    if (w.dbg != 2) {  // wave-uniform dispatch on this wave's tap count
+      f32x16(&a3)[3] = reinterpret_cast<f32x16(&)[3]>(acc);
+      const int(&t3)[3] = reinterpret_cast<const int(&)[3]>(toff);
+      if constexpr (GEO3D) {
+        if (nt == 4) wg3_tile<4>(acc, toff, lds0, ldy0, kh, q, chan_b);
+        else if (nt == 3) wg3_tile<3>(a3, t3, lds0, ldy0, kh, q, chan_b);
+      } else {
+        f32x16(&a2)[2] = reinterpret_cast<f32x16(&)[2]>(acc);
+        const int(&t2)[2] = reinterpret_cast<const int(&)[2]>(toff);
+        f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
+        const int(&t1)[1] = reinterpret_cast<const int(&)[1]>(toff);
+        if (nt == 4) wg_tile<4>(acc, toff, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+        else if (nt == 3) wg_tile<3>(a3, t3, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+        else if (nt == 2) wg_tile<2>(a2, t2, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+        else if (nt == 1) wg_tile<1>(a1, t1, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
       }
     }
     if (next >= w.ntiles) break;
@@ -627,7 +694,7 @@ __global__ void __launch_bounds__(256) k_conv_wgrad(WgradArgs w) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
-    int ti = wave + 4 * t;
+    int ti = wave + 8 * t;
     if (ti >= ntaps) continue;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -658,18 +725,33 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
 }
 
 // dW[co][ci][tap] += sum_split part[split][pair][ti][co_l][ci_l];  uitems[(pair, ti)] = {src_tap, co0, ci0, _}
+// block = 64 elements x 4 split-groups: each thread sums nsplit/4 slabs with 4 independent loads in flight, LDS folds the
+// 4 groups.  (One thread per element walking all slabs serially is pure load latency: 256 dependent round trips.)
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, int64_t split_stride, int nsplit,
                                                       const int* __restrict__ uitems, int nitems, float* __restrict__ dw, int Co_t,
                                                       int Ci_t, int KT) {
-  int64_t gid = blockIdx.x * 256ll + threadIdx.x;
-  int item = (int)(gid >> 10), e = (int)(gid & 1023);
-  if (item >= nitems) return;
-  const int* it = uitems + item * 4;
-  int tap = it[0], co = it[1] + (e >> 5), ci = it[2] + (e & 31);
-  if (tap < 0 || co >= Co_t || ci >= Ci_t) return;
-  float s = 0.f;
-  for (int k = 0; k < nsplit; ++k) s += part[k * split_stride + (int64_t)item * 1024 + e];
-  dw[((int64_t)co * Ci_t + ci) * KT + tap] += s;
+  __shared__ float red[4][64];
+  const int item = blockIdx.x >> 4, e = ((blockIdx.x & 15) << 6) + (threadIdx.x & 63), kg = threadIdx.x >> 6;
+  const float* p = part + (int64_t)item * 1024 + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = kg;
+  for (; k + 12 < nsplit; k += 16) {
+    s0 += p[(int64_t)k * split_stride];
+    s1 += p[(int64_t)(k + 4) * split_stride];
+    s2 += p[(int64_t)(k + 8) * split_stride];
+    s3 += p[(int64_t)(k + 12) * split_stride];
+  }
+  for (; k < nsplit; k += 4) s0 += p[(int64_t)k * split_stride];
+  red[kg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (kg == 0) {
+    const int* it = uitems + item * 4;
+    const int tap = it[0], co = it[1] + (e >> 5), ci = it[2] + (e & 31);
+    if (tap >= 0 && co < Co_t && ci < Ci_t) {
+      const int l = threadIdx.x;
+      dw[((int64_t)co * Ci_t + ci) * KT + tap] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host-side plan
@@ -1082,20 +1164,16 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   const int nvox = a.g.TD * a.g.TH * a.g.TW;
   const int npy = (nvox * 4 + 255) / 256;
   size_t lds = (size_t)a.g.lds_bytes + (size_t)nvox * a.g.vox;
-  dim3 grid(P->wg.ny * P->wg.nchunks, w.nsplit), blk(256);
+  dim3 grid(P->wg.ny * P->wg.nchunks, w.nsplit), blk(512);
   if ((a.g.TD * (a.g.TH / 2) * (a.g.TW / 8)) % 2) return MI_ERR_BAD_ARG;  // the k loop is unrolled in pairs
-  if (npy > 4 || np > 16) return MI_ERR_BAD_ARG;
+  if (npy > 4 || np > 16) return MI_ERR_BAD_ARG;  // (256-thread counts; the kernel runs 512 threads: half of each)
   int max_taps = 0;
   for (size_t i = 1; i < P->wg.hdr.size(); i += 4) max_taps = P->wg.hdr[i] > max_taps ? P->wg.hdr[i] : max_taps;
-#define MI_LAUNCH_WG(NPV)                                                                                          \
+  if (max_taps > 32) return MI_ERR_UNSUPPORTED;
+#define MI_LAUNCH_WG(NPV) MI_LAUNCH_WG_G(NPV, false)
+#define MI_LAUNCH_WG_G(NPV, G3)                                                                                    \
   do {                                                                                                             \
-    if (max_taps <= 4) MI_LAUNCH_WG_T(NPV, 1);                                                                     \
-    else if (max_taps <= 12) MI_LAUNCH_WG_T(NPV, 3);                                                               \
-    else MI_LAUNCH_WG_T(NPV, 7);                                                                                   \
-  } while (0)
-#define MI_LAUNCH_WG_T(NPV, MT)                                                                                    \
-  do {                                                                                                             \
-    auto kern = k_conv_wgrad<NPV, 4, MT>;                                                                          \
+    auto kern = k_conv_wgrad<NPV, 2, G3>;                                                                          \
     static int lds_ok = 0;                                                                                         \
     if ((int)lds > lds_ok) {                                                                                       \
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
@@ -1104,13 +1182,17 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
     }                                                                                                              \
     hipLaunchKernelGGL(kern, grid, blk, lds, st, w);                                                               \
   } while (0)
-  if (np <= 4) MI_LAUNCH_WG(4);
-  else if (np <= 6) MI_LAUNCH_WG(6);
-  else if (np <= 10) MI_LAUNCH_WG(10);
-  else MI_LAUNCH_WG(16);
+  const int np8 = (hv * 4 + 511) / 512;
+  const bool geo3d = P->full27 && a.g.vox == 64 && a.g.row == WG3_XROW && a.g.slice == WG3_XSLICE && a.g.TD == 4 && a.g.TH == 8 &&
+                     a.g.TW == 8 && np8 == 5;
+  if (geo3d) MI_LAUNCH_WG_G(5, true);
+  else if (np8 <= 2) MI_LAUNCH_WG(2);
+  else if (np8 <= 3) MI_LAUNCH_WG(3);
+  else if (np8 <= 5) MI_LAUNCH_WG(5);
+  else MI_LAUNCH_WG(8);
 #undef MI_LAUNCH_WG
-#undef MI_LAUNCH_WG_T
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((int)(((int64_t)P->wg_nitems * 1024 + 255) / 256)), dim3(256), 0, st, P->d_part, P->wg_split_stride,
+#undef MI_LAUNCH_WG_G
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(P->wg_nitems * 16), dim3(256), 0, st, P->d_part, P->wg_split_stride,
                      P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT);
   MI_CHECK_LAUNCH();
   return 0;
