@@ -98,6 +98,15 @@ int mi_transpose_bf16(const void* in, int ld_in, int64_t si1, int64_t si2, void*
 int mi_softmax_fwd(const float* scores, void* probs, int64_t rows, int cols, hipStream_t stream);
 int mi_softmax_bwd(const void* probs, const float* dprobs, void* dscores, int64_t rows, int cols, float scale, hipStream_t stream);
 
+/* ---- fused self-attention (no S x S matrix in HBM) for head dims 32 / 64: AttentionBlock._attention, UNet:406-416 ------------
+ * qkv: [B*S][ld] bf16 rows holding Q | K | V (C columns each, head h at column h*d);  y = softmax(QK^T*scale)V (+ resid);
+ * lse: [B*heads][S] fp32 (log2 domain) saved for the backward;  mi_attn_bwd writes dQ | dK | dV into dqkv (layout of qkv) */
+int mi_attn_supported(int C, int heads);
+int mi_attn_fwd(const void* qkv, int ld, int C, int heads, int B, int S, float scale, const void* resid, void* y, float* lse,
+                hipStream_t stream);
+int mi_attn_bwd(const void* qkv, int ld, int C, int heads, int B, int S, float scale, const void* y, const void* resid, const void* dy,
+                const float* lse, float* dsum, void* dqkv, hipStream_t stream);
+
 /* ---- get_timestep_embedding (UNet:461-485), nn.SiLU on the embedding vector (UNet:1833, 692) --------------------------- */
 int mi_timestep_embedding(const int64_t* timesteps, float* out, int B, int dim, float max_period, hipStream_t stream);
 int mi_silu_f32(const float* x, float* y, int64_t n, hipStream_t stream);

@@ -48,6 +48,9 @@ _SIGS = {
     "mi_transpose_bf16": [_p, _i, _l, _l, _p, _i, _l, _l, _i, _i, _i, _i, _p],
     "mi_softmax_fwd": [_p, _p, _l, _i, _p],
     "mi_softmax_bwd": [_p, _p, _p, _l, _i, _f, _p],
+    "mi_attn_supported": [_i, _i],
+    "mi_attn_fwd": [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p],
+    "mi_attn_bwd": [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p],
     "mi_timestep_embedding": [_p, _p, _i, _i, _f, _p],
     "mi_silu_f32": [_p, _p, _l, _p],
     "mi_silu_bwd_f32": [_p, _p, _p, _l, _p],
@@ -60,7 +63,7 @@ _SIGS = {
     "mi_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _p, _p],
 }
 _RET = {"mi_gn_workspace_bytes": _l}
-_NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes"}
+_NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes", "mi_attn_supported"}
 
 _lib = None
 

@@ -542,6 +542,29 @@ __device__ __forceinline__ void wg_tile(f32x16 (&acc)[NTAP], const int (&toff)[N
   }
 }
 
+// 1-tap pairs (1x1 convs): splitting taps over waves would leave 7 of 8 waves idle, so the 16 k-steps are split instead
+// (wave w takes k-steps 2w, 2w+1) and the 8 partial accumulators are folded through LDS once, after the last tile.
+__device__ __forceinline__ void wg_tile_ksplit(f32x16 (&acc)[1], const int (&toff)[1], const Geom& g, unsigned lds0, unsigned ldy0,
+                                               int kh, int q, int chan_b, int dyrow, int dyslice, int wave) {
+  int sd = 0, sh = 0, sw = 0;
+  auto advance = [&]() {
+    sw += 8;
+    if (sw >= g.TW) { sw = 0; sh += 2; if (sh >= g.TH) { sh = 0; ++sd; } }
+  };
+  for (int i = 0; i < 2 * wave; ++i) advance();
+  const int vox4 = 4 * g.vox;
+  WgFrags<1> fA, fB;
+  wg_issue<1>(fA, ldy0 + sd * dyslice + (sh + kh) * dyrow + (sw + q) * g.vox + chan_b,
+              lds0 + sd * g.slice + (sh + kh) * g.row + (sw + q) * g.vox + chan_b, toff, vox4);
+  advance();
+  wg_issue<1>(fB, ldy0 + sd * dyslice + (sh + kh) * dyrow + (sw + q) * g.vox + chan_b,
+              lds0 + sd * g.slice + (sh + kh) * g.row + (sw + q) * g.vox + chan_b, toff, vox4);
+  wg_wait<1>(fA);
+  wg_wait<1>(fB);
+  wg_mfma<1>(acc, fA);
+  wg_mfma<1>(acc, fB);
+}
+
 // 3-D k3 convs always use the 4x8x8 (+1 halo) tile with 64-byte voxels: row 640, slice 6400 for the x image, 512 / 4096
 // for the dY image.  Every k-step / half-row offset is then a ds_read immediate; one address register per tap, set once.
 constexpr int WG3_XROW = 640, WG3_XSLICE = 6400, WG3_YROW = 512, WG3_YSLICE = 4096;
@@ -621,6 +644,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
     toff[t] = a.taps[tap_begin + (ti < ntaps ? ti : 0)];
     nt += ti < ntaps ? 1 : 0;
   }
+  const bool ksplit = !GEO3D && ntaps == 1;  // 1x1 conv: split the k-steps over the waves instead of the taps
   const int dyrow = g.TW * g.vox, dyslice = g.TH * dyrow;
 
   int tile = blockIdx.y;
@@ -676,7 +700,8 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
         const int(&t2)[2] = reinterpret_cast<const int(&)[2]>(toff);
         f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
         const int(&t1)[1] = reinterpret_cast<const int(&)[1]>(toff);
-        if (nt == 4) wg_tile<4>(acc, toff, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+        if (ksplit) wg_tile_ksplit(a1, t1, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, wave);
+        else if (nt == 4) wg_tile<4>(acc, toff, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
         else if (nt == 3) wg_tile<3>(a3, t3, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
         else if (nt == 2) wg_tile<2>(a2, t2, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
         else if (nt == 1) wg_tile<1>(a1, t1, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
@@ -692,6 +717,21 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
   // partial slab: [tap][co 32][ci 32]; D map: col = lane&31 -> ci, row -> co
   float* out = w.part + (int64_t)blockIdx.y * w.split_stride + w.pair_off[pair];
   const int r = lane & 31, h = lane >> 5;
+  if (ksplit) {  // fold the 8 waves' partial accumulators of the single tap through LDS
+    float* red = (float*)lds;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[0][e];
+    __syncthreads();
+    for (int f = threadIdx.x; f < 1024; f += NT) {
+      float sum = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 8; ++wv) sum += red[wv * 1024 + f];
+      const int e = f >> 6, ln = f & 63;
+      out[((e & 3) + 8 * (e >> 2) + 4 * (ln >> 5)) * 32 + (ln & 31)] = sum;
+    }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
     int ti = wave + 8 * t;

@@ -27,6 +27,46 @@ __device__ __forceinline__ void load_ss(const float* ss, int c0, float* sc, floa
   }
 }
 
+// Block tail: 16 per-thread partials (8 channels x 2 moments) -> out[c][2].  Lanes that own the same 8 channels sit C8
+// apart in a wave, so when C8 is a power of two the voxel lanes are folded with xor-shuffles (log2(64/C8) steps) and LDS only
+// sees one row per wave; otherwise every row goes through LDS.
+__device__ __forceinline__ void block_fold(float (&a)[8], float (&b)[8], float* sm, float* out, int C, int C8, int rows, int r, int cg) {
+  const bool pow2 = (C8 & (C8 - 1)) == 0 && C8 <= 64;
+  if (pow2) {
+    for (int m = C8; m < 64; m <<= 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        a[j] += __shfl_xor(a[j], m, 64);
+        b[j] += __shfl_xor(b[j], m, 64);
+      }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane < C8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sm[(wave * C + lane * 8 + j) * 2] = a[j];
+        sm[(wave * C + lane * 8 + j) * 2 + 1] = b[j];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += kT) out[i] = (sm[i] + sm[2 * C + i]) + (sm[4 * C + i] + sm[6 * C + i]);
+  } else {
+    if (r < rows) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sm[(r * C + cg * 8 + j) * 2] = a[j];
+        sm[(r * C + cg * 8 + j) * 2 + 1] = b[j];
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += kT) {
+      float acc = 0.f;
+      for (int k = 0; k < rows; ++k) acc += sm[k * C * 2 + i];
+      out[i] = acc;
+    }
+  }
+}
+
 // partial[n][chunk][c][2] = (sum x, sum x^2) over the chunk's voxels
 __global__ void __launch_bounds__(kT) k_gn_partial(const bf16* __restrict__ x, int cstride, float* __restrict__ partial, int C,
                                                    int64_t V, int64_t vchunk) {
@@ -58,19 +98,8 @@ __global__ void __launch_bounds__(kT) k_gn_partial(const bf16* __restrict__ x, i
         }
       }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      sm[(r * C + cg * 8 + j) * 2] = s[j];
-      sm[(r * C + cg * 8 + j) * 2 + 1] = q[j];
-    }
   }
-  __syncthreads();
-  float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * C * 2;
-  for (int i = threadIdx.x; i < 2 * C; i += kT) {
-    float a = 0.f;
-    for (int k = 0; k < rows; ++k) a += sm[k * C * 2 + i];
-    out[i] = a;
-  }
+  block_fold(s, q, sm, partial + ((int64_t)n * gridDim.x + blockIdx.x) * C * 2, C, C8, rows, r, cg);
 }
 
 // one block (64 threads) per (n, g)
@@ -165,19 +194,8 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ 
         }
       }
     }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      sm[(r * C + cg * 8 + j) * 2] = s1[j];
-      sm[(r * C + cg * 8 + j) * 2 + 1] = s2[j];
-    }
   }
-  __syncthreads();
-  float* out = partial + ((int64_t)n * gridDim.x + blockIdx.x) * C * 2;
-  for (int i = threadIdx.x; i < 2 * C; i += kT) {
-    float a = 0.f;
-    for (int k = 0; k < rows; ++k) a += sm[k * C * 2 + i];
-    out[i] = a;
-  }
+  block_fold(s1, s2, sm, partial + ((int64_t)n * gridDim.x + blockIdx.x) * C * 2, C, C8, rows, r, cg);
 }
 
 // per (n, g): coefficients of dx = a*du + b*x + c per channel, and the affine-parameter gradients

@@ -14,6 +14,7 @@ import math
 
 import torch
 
+from . import _lib
 from . import hipops as ops
 from ._lib import call, ptr
 
@@ -25,6 +26,8 @@ BF16, F32 = torch.bfloat16, torch.float32
 # use, the standalone pass 54 us once -> standalone is the default; MI_FUSE_PROLOGUE=1 selects the fused path.
 import os as _os
 FUSE_PROLOGUE = _os.environ.get("MI_FUSE_PROLOGUE", "0") == "1"
+# Fused (flash-style) attention for head dims 32 / 64; MI_FLASH_ATTENTION=0 forces the materialised GEMM + softmax path.
+FLASH_ATTENTION = _os.environ.get("MI_FLASH_ATTENTION", "1") == "1"
 
 
 # --------------------------------------------------------------------------------------------- parameters
@@ -110,6 +113,20 @@ class Ctx:
         # algorithmic matmul-class flops of this pass (2*MACs; torch.utils.flop_counter convention)
         self.flops_fwd = 0
         self.flops_bwd = 0
+        # per-conv [N, Cout] fp32 scratch for the fused dy column sums: carved out of ONE buffer that is zeroed by a single
+        # memset when the backward starts (instead of one tiny memset per conv)
+        self._cs_elems = 0
+        self._cs_pool = None
+
+    def cs_reserve(self, nelem):
+        off = self._cs_elems
+        self._cs_elems += (nelem + 3) // 4 * 4
+        return off
+
+    def cs_view(self, off, n, cout, device):
+        if self._cs_pool is None:
+            self._cs_pool = torch.zeros(max(self._cs_elems, 4), dtype=F32, device=device)
+        return self._cs_pool[off:off + n * cout].view(n, cout)
 
     def count(self, fwd_flops, dgrad=True, wgrad=True):
         self.flops_fwd += fwd_flops
@@ -152,6 +169,7 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
     else:
         xin, pn, ps = x, norm, silu
     y = plan.fwd(xin, pn, ps, addvec=av, res=res)
+    cs_off = ctx.cs_reserve(n * cout) if (ctx.tape is not None and d_addvec is None) else -1
     ctx.count(2 * y.numel() * cin * math.prod(kernel), dgrad=need_dx)
     if ctx.tape is not None:
         tape = ctx.tape
@@ -164,8 +182,7 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
             gb = ctx.g(name + ".bias")
             # per-image column sums of dy come out of the wgrad kernel (it holds every dY tile in LDS anyway):
             # they are the time-embedding gradient; the bias gradient is their sum over the batch
-            cs = d_addvec if d_addvec is not None else torch.empty((n, cout), dtype=F32, device=dy.device)
-            ops.zero_f32_2d_(cs)
+            cs = d_addvec if d_addvec is not None else ctx.cs_view(cs_off, n, cout, dy.device)
             plan.wgrad(xin, dy, gw, pn, ps, colsum=cs)
             ops.sum_rows_f32(cs, gb, accumulate=True)
             if res is not None:
@@ -239,6 +256,50 @@ def _transpose(src, ld_in, si1, si2, rows, cols, z, z2, device):
     return out
 
 
+def _attention_flash(ctx, x, name, st, xn, wqkv, qkv, b, s, c, heads, scale):
+    """Head dims 32 / 64: fused attention kernels (csrc/attention.hip); the projections stay on the NT GEMM."""
+    dev = x.device
+    d_, h_, w_ = x.shape[1:4]
+    y = torch.empty_like(x)
+    lse = torch.empty((b * heads, s), dtype=F32, device=dev)
+    call("mi_attn_fwd", ptr(qkv), 3 * c, c, heads, b, s, float(scale), ptr(x), ptr(y), ptr(lse))
+    ctx.count(2 * b * s * c * 3 * c)
+    ctx.count(4 * b * s * s * c)
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is None:
+                return
+            dqkv = torch.empty((b * s, 3 * c), dtype=BF16, device=dev)
+            dsum = torch.empty((b * heads, s), dtype=F32, device=dev)
+            call("mi_attn_bwd", ptr(qkv), 3 * c, c, heads, b, s, float(scale), ptr(y), ptr(x), ptr(dy), ptr(lse), ptr(dsum), ptr(dqkv))
+            _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy, b, s, c)
+
+        tape.record(bwd)
+    return y
+
+
+def _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy, b, s, c):
+    """Shared tail of the attention backward: projection weight/bias gradients, dx through the projections and the norm."""
+    dev = x.device
+    dqkv_t = _transpose(dqkv, 3 * c, 0, 0, b * s, 3 * c, 1, 1, dev)[0]   # [3C, B*S]
+    xn_t = _transpose(xn, c, 0, 0, b * s, c, 1, 1, dev)[0]               # [C, B*S]
+    gw = ctx.arena.span([f"{name}.to_{t}.weight" for t in "qkv"], ctx.arena.grad)
+    _gemm(dqkv_t, b * s, 0, 0, xn_t, b * s, 0, 0, gw, c, 0, 0, 3 * c, c, b * s, 1, 1, accumulate=True)
+    gb = ctx.arena.span([f"{name}.to_{t}.bias" for t in "qkv"], ctx.arena.grad)
+    ops.colsum(dqkv.view(1, 1, 1, b * s, 3 * c), out=gb.view(1, 3 * c), accumulate=True)
+    wqkv_t = _transpose(wqkv, c, 0, 0, 3 * c, c, 1, 1, dev)[0]           # [C, 3C]
+    dxn = torch.empty(x.shape, dtype=BF16, device=dev)
+    _gemm(dqkv, 3 * c, 0, 0, wqkv_t, 3 * c, 0, 0, dxn, c, 0, 0, b * s, c, 3 * c, 1, 1)
+    other = tape.take(x)
+    add = dy if other is None else ops.add(other, dy)
+    dx = ops.gn_bwd(dxn, x, st, ctx.p(name + ".norm.weight"), False, ctx.g(name + ".norm.weight"), ctx.g(name + ".norm.bias"), add=add)
+    tape.grads[id(x)] = dx
+    tape.keep.append(x)
+
+
 def attention(ctx: Ctx, x, name, groups, eps, heads):
     """AttentionBlock.forward (UNet:418-458 / AEKL:283-323): GN -> q,k,v -> softmax(QK^T/sqrt(d)) V -> + x.  No out-proj.
     Channels-last makes the reference's [B,C,S]->[B,S,C] transpose free."""
@@ -255,6 +316,8 @@ def attention(ctx: Ctx, x, name, groups, eps, heads):
     _gemm(xn, c, 0, 0, wqkv, c, 0, 0, qkv, 3 * c, 0, 0, b * s, 3 * c, c, 1, 1, bias=bqkv)
     z = b * heads
     sq = s * 3 * c  # batch stride of qkv
+    if FLASH_ATTENTION and _lib.call_raw("mi_attn_supported", c, heads):
+        return _attention_flash(ctx, x, name, st, xn, wqkv, qkv, b, s, c, heads, scale)
     scores = torch.empty((z, s, s), dtype=F32, device=dev)
     _gemm((qkv, 0), 3 * c, sq, hd, (qkv, c), 3 * c, sq, hd, scores, s, heads * s * s, s * s, s, s, hd, z, heads, alpha=scale)
     probs = ops.softmax_fwd(scores)
@@ -287,23 +350,7 @@ def attention(ctx: Ctx, x, name, groups, eps, heads):
             dot = _transpose((dy, 0), c, s * c, hd, s, hd, z, heads, dev)
             _gemm(pt, s, heads * s * s, s * s, dot, s, heads * hd * s, hd * s, (dqkv, 2 * c), 3 * c, sq, hd, s, hd, s, z, heads)
             del pt
-            # parameter gradients: dW[3C, C] += dqkv^T xn ; db += colsum(dqkv)
-            dqkv_t = _transpose(dqkv, 3 * c, 0, 0, b * s, 3 * c, 1, 1, dev)[0]   # [3C, B*S]
-            xn_t = _transpose(xn, c, 0, 0, b * s, c, 1, 1, dev)[0]               # [C, B*S]
-            gw = ctx.arena.span([f"{name}.to_{t}.weight" for t in "qkv"], ctx.arena.grad)
-            _gemm(dqkv_t, b * s, 0, 0, xn_t, b * s, 0, 0, gw, c, 0, 0, 3 * c, c, b * s, 1, 1, accumulate=True)
-            gb = ctx.arena.span([f"{name}.to_{t}.bias" for t in "qkv"], ctx.arena.grad)
-            ops.colsum(dqkv.view(1, 1, 1, b * s, 3 * c), out=gb.view(1, 3 * c), accumulate=True)
-            # input gradient through the projections and the norm, plus the residual branch
-            wqkv_t = _transpose(wqkv, c, 0, 0, 3 * c, c, 1, 1, dev)[0]           # [C, 3C]
-            dxn = torch.empty((b, d_, h_, w_, c), dtype=BF16, device=dev)
-            _gemm(dqkv, 3 * c, 0, 0, wqkv_t, 3 * c, 0, 0, dxn, c, 0, 0, b * s, c, 3 * c, 1, 1)
-            other = tape.take(x)
-            add = dy if other is None else ops.add(other, dy)
-            dx = ops.gn_bwd(dxn, x, st, ctx.p(name + ".norm.weight"), False, ctx.g(name + ".norm.weight"),
-                            ctx.g(name + ".norm.bias"), add=add)
-            tape.grads[id(x)] = dx
-            tape.keep.append(x)
+            _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy, b, s, c)
 
         tape.record(bwd)
     return y

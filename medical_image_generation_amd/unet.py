@@ -336,7 +336,7 @@ class DiffusionModelUNet(HipModule):
         temb_all, bwd3 = E.linear_f32(se, a.span(wn).view(T, self.temb_dim), a.span(bn), a.span(wn, a.grad).view(T, self.temb_dim),
                                       a.span(bn, a.grad))
         ops.add_f32_(temb_all, a.span([r[0] + ".conv1.conv.bias" for r in self._resnets]))  # fold conv1 biases in
-        d_temb_all = torch.empty_like(temb_all) if grad else None
+        d_temb_all = torch.zeros_like(temb_all) if grad else None  # conv1 wgrads accumulate their dy column sums here
         if grad:
             def bwd_emb():
                 d_se = bwd3(d_temb_all)

@@ -1,0 +1,44 @@
+"""Fused attention kernels (csrc/attention.hip) against a plain PyTorch fp32 reference of softmax(QK^T*scale)V + residual,
+forward and backward, through the C ABI.  bf16 operands, fp32 softmax: |err| <= 2e-2 of the reference's max."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda")
+
+
+@pytest.mark.parametrize("B,H,S,d", [(1, 1, 64, 32), (2, 2, 64, 32), (1, 4, 512, 64), (2, 1, 1000, 64), (1, 2, 4096, 64), (1, 3, 200, 32)])
+def test_flash_attention_fwd_bwd(B, H, S, d):
+    from medical_image_generation_amd._lib import call, ptr
+    C = H * d
+    g = torch.Generator().manual_seed(S + d)
+    qkv = (torch.randn(B, S, 3 * C, generator=g) * 1.5).bfloat16()
+    x = torch.randn(B, S, C, generator=g).bfloat16()
+    dy = torch.randn(B, S, C, generator=g).bfloat16()
+    scale = 1 / math.sqrt(d)
+    # reference (fp32 on the bf16-rounded operands)
+    qr = qkv.float().clone().requires_grad_(True)
+    q, k, v = (qr[..., i * C:(i + 1) * C].reshape(B, S, H, d).permute(0, 2, 1, 3) for i in range(3))
+    att = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+    o = (att @ v).permute(0, 2, 1, 3).reshape(B, S, C)
+    y_ref = o + x.float()
+    o.backward(dy.float())
+    # HIP
+    qd, xd, dyd = qkv.to(dev).reshape(B * S, 3 * C), x.to(dev), dy.to(dev)
+    y = torch.empty_like(xd)
+    lse = torch.empty(B * H, S, device=dev)
+    call("mi_attn_fwd", ptr(qd), 3 * C, C, H, B, S, scale, ptr(xd), ptr(y), ptr(lse))
+    err = float((y.float().cpu() - y_ref.detach()).abs().max())
+    assert err <= 2e-2 * float(y_ref.abs().max()), f"fwd err {err}"
+    lse_ref = torch.logsumexp((q @ k.transpose(-1, -2) * scale).detach(), dim=-1).reshape(B * H, S) / math.log(2)
+    assert float((lse.cpu() - lse_ref).abs().max()) <= 2e-2
+    dqkv = torch.zeros_like(qd)
+    dsum = torch.empty(B * H, S, device=dev)
+    call("mi_attn_bwd", ptr(qd), 3 * C, C, H, B, S, scale, ptr(y), ptr(xd), ptr(dyd), ptr(lse), ptr(dsum), ptr(dqkv))
+    ref = qr.grad.reshape(B * S, 3 * C)
+    got = dqkv.float().cpu()
+    for name, sl in (("dQ", slice(0, C)), ("dK", slice(C, 2 * C)), ("dV", slice(2 * C, 3 * C))):
+        e = float((got[:, sl] - ref[:, sl]).abs().max())
+        assert e <= 2.5e-2 * float(ref[:, sl].abs().max()), f"{name} err {e} vs {float(ref[:, sl].abs().max())}"
