@@ -987,7 +987,8 @@ int launch_igemm_any(const ConvArgs& a, int NCB, int mode, int ntiles, int ny, h
   static const int wps2 = env_int("MI_CONV_NCB2_WPS", 2);  // tuning knob for the 64-cout-per-workgroup variant
   if (mode == 1) {
     if (NCB == 2) return wps2 == 1 ? launch_igemm<2, 2, 3, 1, 1>(a, ntiles, ny, st) : launch_igemm<2, 2, 2, 2, 1>(a, ntiles, ny, st);
-    return launch_igemm<1, 2, 3, 2, 1>(a, ntiles, ny, st);
+    static const int wps1 = env_int("MI_CONV_NCB1_WPS", 2);  // 3: three 53.8 KB workgroups per CU (needs <= 168 VGPRs)
+    return wps1 == 3 ? launch_igemm<1, 2, 2, 3, 1>(a, ntiles, ny, st) : launch_igemm<1, 2, 3, 2, 1>(a, ntiles, ny, st);
   }
   if (mode == 2) {
     if (NCB == 2) return wps2 == 1 ? launch_igemm<2, 2, 3, 1, 2>(a, ntiles, ny, st) : launch_igemm<2, 2, 2, 2, 2>(a, ntiles, ny, st);

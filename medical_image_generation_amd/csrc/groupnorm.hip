@@ -277,8 +277,9 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
 }
 
 inline int64_t pick_vchunk(int64_t V) {
-  int64_t vc = 2048;
-  while ((V + vc - 1) / vc > 1024) vc *= 2;
+  // ~1024 blocks whatever the volume: a 16^3 x 256-channel tensor cut into 2048-voxel chunks would be streamed by 2 CUs
+  int64_t vc = (V + 1023) / 1024;
+  if (vc < 16) vc = 16;
   return vc;
 }
 inline bool bad_c(int C, int G) { return C <= 0 || (C & 7) || C > 2048 || G <= 0 || C % G != 0; }
