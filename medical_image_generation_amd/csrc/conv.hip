@@ -424,7 +424,7 @@ struct WgradArgs {
   float* part;        // [nsplit][npairs][MAXTAPS? -> ntaps_of_pair][32][32] laid out by pair_off
   const int* pair_off;  // [npairs] float offset of the pair's slab inside one split's partial
   int64_t split_stride; // floats per split
-  int ntiles, nsplit;
+  int ntiles, nsplit, npairs;
   int dbg;              // ablation knob (MI_WGRAD_DBG): 1 = stage only the first tile, 2 = skip the MFMA loop
   float* colsum;        // optional: colsum[n * colsum_stride + co] += sum over voxels of dy (bias / time-embedding gradient)
   int colsum_stride;
@@ -621,7 +621,19 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
   char* ldy = lds + g.lds_bytes;  // dY tile image
   typedef __attribute__((address_space(3))) char lds_char;
   const unsigned lds0 = (unsigned)(size_t)(lds_char*)lds, ldy0 = lds0 + g.lds_bytes;
-  const int pair = blockIdx.x;    // (y, chunk)
+  // 1-D grid, XCD-aware: blocks whose ids are equal mod 8 are observed to share an XCD (speed only), and the pairs
+  // (cout block, cin chunk) of ONE tile range read the same x / dY lines -- so they get consecutive slots of one residue
+  // class and hit the same L2 instead of fetching every 64-byte slice of a voxel line through a different one.
+  int pair, split;
+  if (w.nsplit >= 8) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    pair = slot % w.npairs;                 // (y, chunk)
+    split = (slot / w.npairs) * 8 + xcd;    // tile-range index
+  } else {  // few tile ranges (wide layers): every pair reads (nearly) all tiles anyway -- just spread the blocks evenly
+    pair = blockIdx.x / w.nsplit;
+    split = blockIdx.x % w.nsplit;
+  }
+  if (split >= w.nsplit || pair >= w.npairs) return;
   const int y = pair / a.nchunks;
   const int* hdr = a.hdr + (int64_t)pair * 4;
   const int tap_begin = hdr[0], ntaps = hdr[1], src_c0 = hdr[2];
@@ -647,7 +659,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
   const bool ksplit = !GEO3D && ntaps == 1;  // 1x1 conv: split the k-steps over the waves instead of the taps
   const int dyrow = g.TW * g.vox, dyslice = g.TH * dyrow;
 
-  int tile = blockIdx.y;
+  int tile = split;
   if (tile >= w.ntiles) return;
   int n, d0, h0, w0;
   tile_origin(g, tile, n, d0, h0, w0);
@@ -715,7 +727,7 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
     atomicAdd(w.colsum + (int64_t)cs_n * w.colsum_stride + y * 32 + cs_co, cs_acc);
 
   // partial slab: [tap][co 32][ci 32]; D map: col = lane&31 -> ci, row -> co
-  float* out = w.part + (int64_t)blockIdx.y * w.split_stride + w.pair_off[pair];
+  float* out = w.part + (int64_t)split * w.split_stride + w.pair_off[pair];
   const int r = lane & 31, h = lane >> 5;
   if (ksplit) {  // fold the 8 waves' partial accumulators of the single tap through LDS
     float* red = (float*)lds;
@@ -1205,7 +1217,8 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   const int nvox = a.g.TD * a.g.TH * a.g.TW;
   const int npy = (nvox * 4 + 255) / 256;
   size_t lds = (size_t)a.g.lds_bytes + (size_t)nvox * a.g.vox;
-  dim3 grid(P->wg.ny * P->wg.nchunks, w.nsplit), blk(512);
+  w.npairs = P->wg.ny * P->wg.nchunks;
+  dim3 grid(w.nsplit >= 8 ? w.npairs * ((w.nsplit + 7) / 8) * 8 : w.npairs * w.nsplit), blk(512);
   if ((a.g.TD * (a.g.TH / 2) * (a.g.TW / 8)) % 2) return MI_ERR_BAD_ARG;  // the k loop is unrolled in pairs
   if (npy > 4 || np > 16) return MI_ERR_BAD_ARG;  // (256-thread counts; the kernel runs 512 threads: half of each)
   int max_taps = 0;

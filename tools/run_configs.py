@@ -1,0 +1,56 @@
+"""Run the other BASELINE.json configs through the fused HIP trainer and report ms/step (sanity + scale check).
+usage: python tools/run_configs.py c2|c3b|c5 [steps]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from medical_image_generation_amd import engine as E
+from medical_image_generation_amd.trainer import DDPMTrainer
+from medical_image_generation_amd.unet import DiffusionModelUNet
+
+which = sys.argv[1]
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+iso = lambda n: [[1] * 3] + [[2] * 3] * (n - 1)
+if which == "c2":   # 3D DDPM 96^3, batch 2 (BASELINE configs[1])
+    kw = dict(spatial_dims=3, in_channels=1, out_channels=1, num_res_blocks=2, num_channels=(32, 64, 128, 256),
+              attention_levels=(False, False, False, True), num_head_channels=(0, 0, 0, 64), norm_num_groups=32,
+              strides=iso(4), kernel_sizes=[[3] * 3] * 4, paddings=[[1] * 3] * 4)
+    shape, vox_per_sample = (2, 1, 96, 96, 96), 96 ** 3
+elif which in ("c3b", "c5"):  # latent UNet the reference's planner emits (CFG:876-902); C5: 40^3 latents (160^3 patch), +1 label channel
+    cin = 8 if which == "c3b" else 9
+    kw = dict(spatial_dims=3, in_channels=cin, out_channels=8 if which == "c3b" else 9, num_res_blocks=2, num_channels=[256, 512, 768],
+              attention_levels=[False, True, True], num_head_channels=[0, 512, 768], norm_num_groups=32,
+              strides=iso(3), kernel_sizes=[[3] * 3] * 3, paddings=[[1] * 3] * 3)
+    shape = (4, 8, 32, 32, 32) if which == "c3b" else (1, 9, 40, 40, 40)
+    vox_per_sample = 128 ** 3 if which == "c3b" else 160 ** 3
+dev = torch.device("cuda")
+torch.manual_seed(0)
+net = DiffusionModelUNet(**kw)
+for p in net.parameters():
+    if float(p.detach().abs().max()) == 0:
+        torch.nn.init.normal_(p, std=0.02)
+net = net.to(dev)
+tr = DDPMTrainer(net, lr=2e-5)
+x0 = torch.rand(shape, device=dev)
+noise = torch.randn(shape, device=dev)
+t = torch.randint(0, 1000, (shape[0],), device=dev)
+tr.capture(x0, noise, t)
+for _ in range(2):
+    tr.step_graph()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    loss = tr.step_graph()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+c = E.Ctx(tr.arena, net._plans, grad_enabled=True)
+dims = (shape[0],) + tuple(shape[2:]) + (shape[1],)
+net._run(c, torch.zeros(dims, dtype=torch.bfloat16, device=dev), t, need_dx=False)
+c.tape.fns.clear()
+fl = c.flops_fwd + c.flops_bwd
+print(json.dumps({"config": which, "ms_per_step": dt * 1e3, "voxels_per_s": shape[0] * vox_per_sample / dt, "loss": float(loss),
+                  "params": sum(p.numel() for p in net.parameters()), "model_flops_per_step": fl, "mfma_frac": fl / dt / 2.5e15,
+                  "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
