@@ -1,19 +1,48 @@
-"""Body of __graft_entry__.smoke(): placeholder until the network path lands -- one fused conv vs torch fp32."""
-import math
-
+"""Body of __graft_entry__.smoke(): one tiny forward+backward of the 3-D DDPM U-Net through the HIP path on cuda:0, checked
+against the CPU oracle, plus one fused train step (q-sample -> UNet -> MSE -> backward -> clip -> AdamW)."""
 import torch
-import torch.nn.functional as F
 
 
 def run():
-    from medical_image_generation_amd import hipops as ops
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
-    x = torch.randn(1, 32, 8, 8, 8).bfloat16().float()
-    w = (torch.randn(32, 32, 3, 3, 3) / math.sqrt(27 * 32)).bfloat16().float()
-    plan = ops.ConvPlan(1, (8, 8, 8), 32, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1))
-    plan.pack(w.to(dev))
-    y = plan.fwd(x.permute(0, 2, 3, 4, 1).contiguous().to(dev, torch.bfloat16))
-    ref = F.conv3d(x, w, padding=1)
-    err = float((y.float().cpu().permute(0, 4, 1, 2, 3) - ref).abs().max())
-    assert err <= 1e-2 * float(ref.abs().max()), err
+    from medical_image_generation_amd.trainer import DDPMTrainer
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    from oracle import cases, nets, step, synth
+
+    S = cases.SEED
+    c = cases.UNET_CASES["unet3d"]
+    ref = nets.DiffusionModelUNet(**c["kwargs"])
+    sd = synth.state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, S)
+    ref.load_state_dict(sd)
+    net = DiffusionModelUNet(**c["kwargs"])
+    net.load_state_dict(sd)
+    net = net.to("cuda:0")
+    x = synth.tensor(S, "x", c["shape"])
+    t = torch.tensor(c["timesteps"])
+    gy = synth.tensor(S, "grad_out", c["shape"])
+    xd = x.to("cuda:0").requires_grad_(True)
+    pred = net(xd, t.to("cuda:0"))
+    pred.backward(gy.to("cuda:0"))
+    xr = x.clone().requires_grad_(True)
+    pr = ref(xr, t)
+    pr.backward(gy)
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / b.double().norm())
+
+    e_pred, e_dx = rel(pred.detach().cpu(), pr.detach()), rel(xd.grad.cpu(), xr.grad)
+    gr = torch.cat([p.grad.flatten() for n, p in sorted(ref.named_parameters()) if p.grad is not None])
+    gh = torch.cat([p.grad.cpu().flatten() for n, p in sorted(net.named_parameters()) if p.grad is not None])
+    e_g = rel(gh, gr)
+    print(f"smoke: rel-L2 vs oracle  pred {e_pred:.3e}  dx {e_dx:.3e}  grads {e_g:.3e}")
+    assert e_pred < 3e-2 and e_dx < 3e-2 and e_g < 4e-2
+    # one fused train step against the oracle's step
+    net.zero_grad(set_to_none=True)
+    tr = DDPMTrainer(net, lr=1e-3, optimizer="AdamW")
+    x0 = synth.ellipsoid_volume(S, "x0", c["shape"])
+    noise = synth.tensor(S, "noise0", c["shape"])
+    loss = float(tr.step(x0.to("cuda:0"), noise.to("cuda:0"), t.to("cuda:0")))
+    ref.zero_grad(set_to_none=True)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+    loss_ref, _ = step.ddpm_train_step(ref, opt, step.DDPMSchedule(), x0, noise, t, max_norm=1.0)
+    print(f"smoke: train-step loss hip {loss:.5f} oracle {float(loss_ref):.5f}")
+    assert abs(loss - float(loss_ref)) <= 1e-2 * abs(float(loss_ref))
