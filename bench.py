@@ -106,12 +106,16 @@ def main():
         return
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("MI_DIST_BACKEND", "nccl")  # "nccl" = RCCL over xGMI; "gloo" only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from medical_image_generation_amd.trainer import DDPMTrainer
@@ -132,8 +136,12 @@ def main():
     use_graph = not args.no_graph
     noise.normal_(generator=gen), t.random_(0, 1000, generator=gen)
     if use_graph:
-        tr.capture(x0, noise, t)
-        _, noise, t = tr._static  # the graphs read these buffers: fresh noise / timesteps are drawn INTO them each step
+        try:
+            tr.capture(x0, noise, t)
+            _, noise, t = tr._static  # the graphs read these buffers: fresh noise / timesteps are drawn INTO them each step
+        except Exception as exc:  # capture is an optimisation: never let it take the run down
+            print(f"[bench] hipGraph capture failed ({type(exc).__name__}: {exc}); running eager", file=sys.stderr, flush=True)
+            use_graph = False
 
     def one_step(use_graph):
         noise.normal_(generator=gen)
@@ -159,6 +167,9 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+        ok = torch.tensor([1.0 if use_graph else 0.0], device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        use_graph = bool(ok.item())
     voxels = world * args.batch * args.size ** 3 * args.steps
 
     if rank == 0:

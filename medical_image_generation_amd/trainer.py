@@ -123,11 +123,12 @@ class DDPMTrainer:
                 self.forward_backward(*self._static)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        # thread_local: a collective library's watchdog thread polling events must not invalidate the capture
         self._g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_fb):
+        with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
             self.forward_backward(*self._static)
         self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt):
+        with torch.cuda.graph(self._g_opt, capture_error_mode="thread_local"):
             self.optimizer_step()
         self._graph = True
 
