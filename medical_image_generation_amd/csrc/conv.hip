@@ -63,6 +63,7 @@ struct ConvArgs {
   const float* addvec; int addvec_stride;   // fp32 [Cout] (stride 0) or [N] rows of pitch `stride`; null = none
   const bf16* res; int res_cs;
   int ntiles;
+  int dbg;  // ablation knob (MI_IGEMM_DBG): 1 = stage only the first image, 2 = skip the MFMA loop, 3 = skip the epilogue
   unsigned x_bytes, wpk_bytes;  // sizes for the buffer descriptors (both < 4 GiB, checked on the host)
   Geom g;
 };
@@ -286,6 +287,7 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {
   stage_init<NP>(st, g);
   stage_load<NP>(st, a, n, d0, h0, w0, hdr[2]);
   int n_pre = n;  // batch index of the data held in st.pre
+  bool first_img = true;
 
   while (true) {
     f32x16 acc[VB][NCB];
@@ -314,16 +316,20 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {
             for (int cb = 0; cb < NCB; ++cb) wa[q][ks][cb] = buf_load16(rw, wlane, wsoff + ((q * 2 + ks) * NCB + cb) * 1024u);
         }
       __syncthreads();  // every wave is done reading the previous tile image
-      stage_store<NP>(st, a, n_pre, src_c0, lds);
+      if (a.dbg != 1 || first_img) stage_store<NP>(st, a, n_pre, src_c0, lds);
       __syncthreads();
+      first_img = false;
       // next image (next chunk of this tile, or chunk 0 of this workgroup's next tile): in flight under the MFMAs below
-      if (ch + 1 < a.nchunks) {
+      if (a.dbg == 1) {
+        if (ch + 1 >= a.nchunks && next_tile < tile_last) tile_origin(g, next_tile, nn, nd0, nh0, nw0);
+      } else if (ch + 1 < a.nchunks) {
         stage_load<NP>(st, a, n, d0, h0, w0, hdr[(ch + 1) * 4 + 2]);
       } else if (next_tile < tile_last) {
         tile_origin(g, next_tile, nn, nd0, nh0, nw0);
         stage_load<NP>(st, a, nn, nd0, nh0, nw0, hdr[2]);
         n_pre = nn;
       }
+      if (a.dbg == 2) continue;
       if constexpr (FULL27) {
         // k3 s1 in all three axes: the 27 taps are a compile-time loop nest (offsets = i*slice + j*row + k*VOXB, mirrored
         // for the data gradient), so the whole chunk is straight-line code the scheduler can software-pipeline.
@@ -373,6 +379,7 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {
     }
 
     // epilogue: lane holds voxel r of each block, channels co_base + 8*grp + 4*h + (0..3) for grp = 0..3
+    if (a.dbg != 3)
 #pragma unroll
     for (int vb = 0; vb < VB; ++vb) {
       const int od = d0 + bvd[vb], oh = h0 + bvh[vb], ow = w0 + bvw[vb];
@@ -951,12 +958,19 @@ void free_tables(Tables& T) {
   if (T.d_wpk) (void)hipFree(T.d_wpk);
 }
 
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 template <int NCB, int VB, int RING, int WPS, int MODE>
 int launch_igemm(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   if (MODE != 0 && (a.g.row != F27_ROW || a.g.slice != F27_SLICE || a.g.TD != 4 || a.g.TH != 8 || a.g.TW != 8)) return MI_ERR_BAD_ARG;
   const int hv = a.g.HD * a.g.HH * a.g.HW;
   const int np = (hv * 4 + 255) / 256;
   a.ntiles = ntiles;
+  static const int dbg = env_int("MI_IGEMM_DBG", 0);
+  a.dbg = dbg;
   // persistent grid: ~2 workgroups per CU in total, a multiple of 8 per cout group (one slot set per XCD residue class)
   int gx = (256 * WPS / ny + 7) / 8 * 8;
   if (gx < 8) gx = 8;
@@ -990,21 +1004,17 @@ int launch_igemm(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   return 0;
 }
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 int launch_igemm_any(const ConvArgs& a, int NCB, int mode, int ntiles, int ny, hipStream_t st) {
   static const int wps2 = env_int("MI_CONV_NCB2_WPS", 2);  // tuning knob for the 64-cout-per-workgroup variant
   if (mode == 1) {
     if (NCB == 2) return wps2 == 1 ? launch_igemm<2, 2, 3, 1, 1>(a, ntiles, ny, st) : launch_igemm<2, 2, 2, 2, 1>(a, ntiles, ny, st);
-    static const int wps1 = env_int("MI_CONV_NCB1_WPS", 2);  // 3: three 53.8 KB workgroups per CU (needs <= 168 VGPRs)
-    return wps1 == 3 ? launch_igemm<1, 2, 2, 3, 1>(a, ntiles, ny, st) : launch_igemm<1, 2, 3, 2, 1>(a, ntiles, ny, st);
+    static const int ring1 = env_int("MI_CONV_NCB1_RING", 3);  // weight-fragment ring depth (taps) of the 32-cout variant
+    return ring1 == 3 ? launch_igemm<1, 2, 3, 2, 1>(a, ntiles, ny, st) : launch_igemm<1, 2, 6, 2, 1>(a, ntiles, ny, st);
   }
   if (mode == 2) {
     if (NCB == 2) return wps2 == 1 ? launch_igemm<2, 2, 3, 1, 2>(a, ntiles, ny, st) : launch_igemm<2, 2, 2, 2, 2>(a, ntiles, ny, st);
-    return launch_igemm<1, 2, 3, 2, 2>(a, ntiles, ny, st);
+    static const int ring1 = env_int("MI_CONV_NCB1_RING", 3);
+    return ring1 == 3 ? launch_igemm<1, 2, 3, 2, 2>(a, ntiles, ny, st) : launch_igemm<1, 2, 6, 2, 2>(a, ntiles, ny, st);
   }
   if (NCB == 2) return launch_igemm<2, 2, 2, 2, 0>(a, ntiles, ny, st);
   return launch_igemm<1, 2, 4, 2, 0>(a, ntiles, ny, st);

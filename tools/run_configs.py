@@ -13,6 +13,48 @@ from medical_image_generation_amd.unet import DiffusionModelUNet
 
 which = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+
+
+def run_c3a():
+    """AutoencoderKL exactly as CFG:821-862 emits it for a 128^3 single-channel dataset (BASELINE configs[2], AE half):
+    autograd path -- encode / decode are HIP autograd edges, L1 + kl_weight*KL and Adam are torch (T-AE:411-414, 470)."""
+    from medical_image_generation_amd.autoencoderkl import AutoencoderKL
+    down = [[[1] * 3, [3] * 3, [1] * 3], [[2] * 3, [3] * 3, [1] * 3], [[2] * 3, [3] * 3, [1] * 3]]
+    kw = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=8, num_res_blocks=2, num_channels=[32, 64, 128],
+              attention_levels=[False] * 3, norm_num_groups=16, with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False,
+              downsample_parameters=down, upsample_parameters=list(reversed(down))[:-1])
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    net = AutoencoderKL(**kw).to(dev)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-5)
+    x = torch.rand((2, 1, 128, 128, 128), device=dev)
+
+    def one():
+        recon, mu, sigma = net(x)
+        kl = 0.5 * (mu.pow(2) + sigma.pow(2) - torch.log(sigma.pow(2)) - 1).sum(dim=[1, 2, 3, 4]).sum() / mu.shape[0]
+        loss = torch.nn.functional.l1_loss(recon.float(), x) + 1e-7 * kl
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 1.0)
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        return loss
+
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    print(json.dumps({"config": "c3a", "ms_per_step": dt * 1e3, "voxels_per_s": 2 * 128 ** 3 / dt, "loss": float(loss),
+                      "params": sum(p.numel() for p in net.parameters()), "model_flops_per_step_survey": 1.497e13,
+                      "mfma_frac": 1.497e13 / dt / 2.5e15, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+
+
+if which == "c3a":
+    run_c3a()
+    sys.exit(0)
 iso = lambda n: [[1] * 3] + [[2] * 3] * (n - 1)
 if which == "c2":   # 3D DDPM 96^3, batch 2 (BASELINE configs[1])
     kw = dict(spatial_dims=3, in_channels=1, out_channels=1, num_res_blocks=2, num_channels=(32, 64, 128, 256),
