@@ -767,10 +767,17 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
 // frag_items[f] = {src_tap, co0, ci0, flags}: fragment f holds A[row = co0 + r][k = ci0 + 8h + j] (kernel channel indices);
 // torch weight W[Co_t][Ci_t][KT]; flags bit0: transposed (kernel-out = torch-in), i.e. dgrad.
 __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, u32x4* __restrict__ out,
-                                                      const int* __restrict__ items, int nfrags, int Co_t, int Ci_t, int KT) {
+                                                      const int* __restrict__ items, int nfrags, u32x4* __restrict__ out2,
+                                                      const int* __restrict__ items2, int nfrags2, int Co_t, int Ci_t, int KT) {
+  // one launch packs BOTH fragment tables of a conv (forward, then data-gradient)
   int gid = blockIdx.x * 256 + threadIdx.x;
   int f = gid >> 6, lane = gid & 63;
-  if (f >= nfrags) return;
+  if (f >= nfrags) {
+    f -= nfrags;
+    if (f >= nfrags2) return;
+    out = out2; items = items2;
+    gid = f * 64 + lane;
+  }
   const int* it = items + f * 4;
   int tap = it[0], co = it[1] + (lane & 31), ci0 = it[2] + (lane >> 5) * 8, tr = it[3] & 1;
   F8 v;
@@ -1116,10 +1123,8 @@ int mi_conv_plan_out_dims(const mi_conv_plan* P, int* dims3) {
 // fp32 master weight [Cout][Cin][kd][kh][kw] -> packed bf16 fragments for forward and dgrad
 int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
   if (!P || !w) return MI_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_pack_weights, dim3((P->fwd.nfrags * 64 + 255) / 256), dim3(256), 0, st, w, P->fwd.d_wpk, P->fwd.d_items, P->fwd.nfrags,
-                     P->Cout, P->Cin, P->KT);
-  hipLaunchKernelGGL(k_pack_weights, dim3((P->dg.nfrags * 64 + 255) / 256), dim3(256), 0, st, w, P->dg.d_wpk, P->dg.d_items, P->dg.nfrags,
-                     P->Cout, P->Cin, P->KT);
+  hipLaunchKernelGGL(k_pack_weights, dim3(((P->fwd.nfrags + P->dg.nfrags) * 64 + 255) / 256), dim3(256), 0, st, w, P->fwd.d_wpk,
+                     P->fwd.d_items, P->fwd.nfrags, P->dg.d_wpk, P->dg.d_items, P->dg.nfrags, P->Cout, P->Cin, P->KT);
   MI_CHECK_LAUNCH();
   return 0;
 }

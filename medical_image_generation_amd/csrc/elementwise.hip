@@ -412,7 +412,8 @@ int mi_colsum_bf16(const void* x, float* out, int out_stride, int N, int64_t V, 
   int threads = 256;
   if (C8 > threads) threads = ((C8 + 63) / 64) * 64;
   int rows = threads / C8;
-  int64_t vchunk = 2048;
+  int64_t vchunk = (V + 511) / 512;  // ~512 blocks whatever the shape (a [4096 x 768] matrix in 2048-row chunks = 2 blocks)
+  if (vchunk < 16) vchunk = 16;
   int chunks = ceil_div(V, vchunk);
   hipLaunchKernelGGL(k_colsum, dim3(chunks, N), dim3(threads), sizeof(float) * (size_t)rows * C, st, (const bf16*)x, out, out_stride, C, V, vchunk);
   MI_CHECK_LAUNCH();

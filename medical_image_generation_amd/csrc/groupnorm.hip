@@ -102,24 +102,37 @@ __global__ void __launch_bounds__(kT) k_gn_partial(const bf16* __restrict__ x, i
   block_fold(s, q, sm, partial + ((int64_t)n * gridDim.x + blockIdx.x) * C * 2, C, C8, rows, r, cg);
 }
 
-// one block (64 threads) per (n, g)
-__global__ void k_gn_finalize(const float* __restrict__ partial, int chunks, int C, int G, int64_t V, float eps,
-                              const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ scale_shift,
-                              float* __restrict__ mean_rstd) {
+// one block (256 threads) per (n, g): up to 1024 chunk partials per channel, so the loads are spread over 4 waves
+__device__ __forceinline__ void block_sum2_d(double& a, double& b, double* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[(threadIdx.x >> 6) * 2] = a;
+    red[(threadIdx.x >> 6) * 2 + 1] = b;
+  }
+  __syncthreads();
+  a = (red[0] + red[2]) + (red[4] + red[6]);
+  b = (red[1] + red[3]) + (red[5] + red[7]);
+}
+
+__global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ partial, int chunks, int C, int G, int64_t V, float eps,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ scale_shift, float* __restrict__ mean_rstd) {
+  __shared__ double red[8];
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   double s = 0.0, q = 0.0;
-  for (int i = threadIdx.x; i < chunks * cpg; i += 64) {
+  for (int i = threadIdx.x; i < chunks * cpg; i += 256) {
     int ch = i / cpg, c = g * cpg + i % cpg;
     const float* p = partial + (((int64_t)n * chunks + ch) * C + c) * 2;
     s += (double)p[0];
     q += (double)p[1];
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    s += __shfl_xor(s, off, 64);
-    q += __shfl_xor(q, off, 64);
-  }
+  block_sum2_d(s, q, red);
   const double m = (double)V * cpg;
   const double mean = s / m;
   double var = q / m - mean * mean;
@@ -129,7 +142,7 @@ __global__ void k_gn_finalize(const float* __restrict__ partial, int chunks, int
     mean_rstd[((int64_t)n * G + g) * 2] = (float)mean;
     mean_rstd[((int64_t)n * G + g) * 2 + 1] = rstd;
   }
-  for (int i = threadIdx.x; i < cpg; i += 64) {
+  for (int i = threadIdx.x; i < cpg; i += 256) {
     int c = g * cpg + i;
     float sc = gamma[c] * rstd;
     scale_shift[((int64_t)n * C + c) * 2] = sc;
@@ -199,27 +212,24 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ 
 }
 
 // per (n, g): coefficients of dx = a*du + b*x + c per channel, and the affine-parameter gradients
-__global__ void k_gn_bwd_finalize(const float* __restrict__ partial, int chunks, int C, int G, int64_t V,
-                                  const float* __restrict__ gamma, const float* __restrict__ mean_rstd, float* __restrict__ coef,
-                                  float* __restrict__ dgamma, float* __restrict__ dbeta) {
+__global__ void __launch_bounds__(256) k_gn_bwd_finalize(const float* __restrict__ partial, int chunks, int C, int G, int64_t V,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                         float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   extern __shared__ float sm[];  // [cpg][2] channel sums
+  __shared__ double red[8];
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const float mean = mean_rstd[((int64_t)n * G + g) * 2], rstd = mean_rstd[((int64_t)n * G + g) * 2 + 1];
   double m1 = 0.0, m2 = 0.0;
-  for (int i = 0; i < cpg; ++i) {  // channels of the group in turn; the 64 lanes split the chunks
+  for (int i = 0; i < cpg; ++i) {  // channels of the group in turn; the 256 threads split the chunks
     int c = g * cpg + i;
     double s1 = 0.0, s2 = 0.0;
-    for (int ch = threadIdx.x; ch < chunks; ch += 64) {
+    for (int ch = threadIdx.x; ch < chunks; ch += 256) {
       const float* p = partial + (((int64_t)n * chunks + ch) * C + c) * 2;
       s1 += (double)p[0];
       s2 += (double)p[1];
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      s1 += __shfl_xor(s1, off, 64);
-      s2 += __shfl_xor(s2, off, 64);
-    }
+    block_sum2_d(s1, s2, red);
     double s2hat = (double)rstd * (s2 - (double)mean * s1);  // sum du * xhat
     if (threadIdx.x == 0) {
       sm[2 * i] = (float)s1;
@@ -234,7 +244,7 @@ __global__ void k_gn_bwd_finalize(const float* __restrict__ partial, int chunks,
   m2 /= m;
   const float b = (float)(-(double)rstd * rstd * m2);
   const float c0 = (float)((double)rstd * rstd * m2 * mean - (double)rstd * m1);
-  for (int i = threadIdx.x; i < cpg; i += 64) {
+  for (int i = threadIdx.x; i < cpg; i += 256) {
     int c = g * cpg + i;
     float* o = coef + ((int64_t)n * C + c) * 3;
     o[0] = rstd * gamma[c];
@@ -302,7 +312,7 @@ int mi_gn_stats(const void* x, int x_cstride, int N, int64_t V, int C, int G, fl
   int rows = kT / (C / 8);
   hipLaunchKernelGGL(k_gn_partial, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)x, x_cstride,
                      (float*)workspace, C, V, vc);
-  hipLaunchKernelGGL(k_gn_finalize, dim3(N * G), dim3(64), 0, st, (const float*)workspace, chunks, C, G, V, eps, gamma, beta,
+  hipLaunchKernelGGL(k_gn_finalize, dim3(N * G), dim3(256), 0, st, (const float*)workspace, chunks, C, G, V, eps, gamma, beta,
                      scale_shift, mean_rstd);
   MI_CHECK_LAUNCH();
   return 0;
@@ -331,7 +341,7 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   int rows = kT / (C / 8);
   hipLaunchKernelGGL(k_gn_bwd_partial, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride,
                      (const bf16*)x, x_cstride, scale_shift, (float*)workspace, C, V, vc, silu);
-  hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(N * G), dim3(64), sizeof(float) * 2 * (size_t)(C / G), st, (const float*)workspace, chunks, C,
+  hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(N * G), dim3(256), sizeof(float) * 2 * (size_t)(C / G), st, (const float*)workspace, chunks, C,
                      G, V, gamma, mean_rstd, coef, dgamma, dbeta);
   int64_t total = (int64_t)N * V * (C / 8);
   int64_t grid = (total + kT - 1) / kT;
