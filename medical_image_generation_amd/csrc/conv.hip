@@ -209,11 +209,22 @@ __device__ __forceinline__ void lds_wait_frags(u32x4 (&f)[2][VB]) {
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0][0]), "+v"(f[1][0]));
   __builtin_amdgcn_sched_barrier(0);
 }
+// wait for one fragment set while the NEXT set's 2*VB reads (issued after it; LDS returns in order) stay in flight
+template <int VB>
+__device__ __forceinline__ void lds_wait_frags_keep1(u32x4 (&f)[2][VB]) {
+  if constexpr (VB == 2)
+    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(f[0][0]), "+v"(f[0][1]), "+v"(f[1][0]), "+v"(f[1][1]));
+  else
+    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(f[0][0]), "+v"(f[1][0]));
+  __builtin_amdgcn_sched_barrier(0);
+}
 
 template <int OFF>
 __device__ __forceinline__ void lds_read16_async(u32x4& dst, unsigned addr);
 template <int VB>
 __device__ __forceinline__ void lds_wait_frags(u32x4 (&f)[2][VB]);
+template <int VB>
+__device__ __forceinline__ void lds_wait_frags_keep1(u32x4 (&f)[2][VB]);
 
 constexpr int F27_ROW = 896, F27_SLICE = 8960;  // LDS pitches of the 4x8x8 (+1 halo) tile every k3-s1 3-D conv uses
 template <int T, int FLIP>
@@ -254,6 +265,34 @@ __device__ __forceinline__ void f27_taps(f32x16 (&acc)[VB][NCB], u32x4 (&wa)[RIN
     }
     if constexpr (T + 1 < 27) lds_wait_frags<VB>(fb[cur ^ 1]);
     f27_taps<T + 1, NCB, VB, RING, FLIP>(acc, wa, fb, baddr, rw, wsoff);
+  }
+}
+
+// lookahead-2 variant: three fragment sets; while tap T computes, taps T+1 and T+2 are in flight
+template <int T, int NCB, int VB, int RING, int FLIP>
+__device__ __forceinline__ void f27_taps3(f32x16 (&acc)[VB][NCB], u32x4 (&wa)[RING][2][NCB], u32x4 (&fb)[3][2][VB],
+                                          const unsigned (&baddr)[VB], __amdgpu_buffer_rsrc_t rw, unsigned wsoff) {
+  if constexpr (T < 27) {
+    constexpr int q = T % RING, cur = T % 3;
+    if constexpr (T + 2 < 27) f27_issue<T + 2, FLIP, VB>(fb[(T + 2) % 3], baddr);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int vb = 0; vb < VB; ++vb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          acc[vb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wa[q][ks][cb]),
+                                                                __builtin_bit_cast(bf16x8, fb[cur][ks][vb]), acc[vb][cb], 0, 0, 0);
+    if constexpr (T + RING < 27) {
+      const unsigned wlane = (threadIdx.x & 63) * 16u;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) wa[q][ks][cb] = buf_load16(rw, wlane, wsoff + (((T + RING) * 2 + ks) * NCB + cb) * 1024u);
+    }
+    if constexpr (T + 2 < 27) lds_wait_frags_keep1<VB>(fb[(T + 1) % 3]);
+    else if constexpr (T + 1 < 27) lds_wait_frags<VB>(fb[(T + 1) % 3]);
+    f27_taps3<T + 1, NCB, VB, RING, FLIP>(acc, wa, fb, baddr, rw, wsoff);
   }
 }
 
@@ -344,10 +383,18 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {
           baddr[vb] = lds0 + bbase[vb];
           asm volatile("" : "+v"(baddr[vb]));  // keep it ONE register: no per-tap address hoisting
         }
-        u32x4 fb[2][2][VB];
-        f27_issue<0, FLIP, VB>(fb[0], baddr);
-        lds_wait_frags<VB>(fb[0]);
-        f27_taps<0, NCB, VB, RING, FLIP>(acc, wa, fb, baddr, rw, wsoff);
+        if constexpr (NCB == 1) {  // registers to spare: look two taps ahead
+          u32x4 fb[3][2][VB];
+          f27_issue<0, FLIP, VB>(fb[0], baddr);
+          f27_issue<1, FLIP, VB>(fb[1], baddr);
+          lds_wait_frags_keep1<VB>(fb[0]);
+          f27_taps3<0, NCB, VB, RING, FLIP>(acc, wa, fb, baddr, rw, wsoff);
+        } else {
+          u32x4 fb[2][2][VB];
+          f27_issue<0, FLIP, VB>(fb[0], baddr);
+          lds_wait_frags<VB>(fb[0]);
+          f27_taps<0, NCB, VB, RING, FLIP>(acc, wa, fb, baddr, rw, wsoff);
+        }
       } else {
       for (int t0 = 0; t0 < ntaps; t0 += RING) {
 #pragma unroll

@@ -1,0 +1,112 @@
+"""Per-call timing of one eager C4 train step: every C-ABI call is bracketed by HIP events on its launch stream and the
+totals are printed per (entry point, shape label).  Conv calls are labelled with their layer shape.
+
+  python tools/profile_step.py [size] [steps]
+"""
+import collections
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from medical_image_generation_amd import _lib, engine, hipops, trainer  # noqa: E402
+from medical_image_generation_amd.unet import DiffusionModelUNet  # noqa: E402
+
+size = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = torch.device("cuda")
+records = []
+label = [None]
+enabled = [False]
+_orig_call = _lib.call
+
+
+def timed_call(name, *args):
+    if not enabled[0]:
+        return _orig_call(name, *args)
+    st = torch.cuda.current_stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    _orig_call(name, *args)
+    e1.record(st)
+    records.append((name, label[0], e0, e1))
+
+
+for mod in (_lib, engine, hipops, trainer):
+    mod.call = timed_call
+
+
+def wrap(method, kind):
+    orig = getattr(hipops.ConvPlan, method)
+
+    def f(self, *a, **k):
+        label[0] = f"{self.cin}->{self.cout} k{self.kernel[-1]} s{self.stride[-1]} @{self.dims[-1]}"
+        try:
+            return orig(self, *a, **k)
+        finally:
+            label[0] = None
+
+    setattr(hipops.ConvPlan, method, f)
+
+
+for m in ("fwd", "dgrad", "wgrad", "pack"):
+    wrap(m, m)
+
+
+def wrap_shape(fname):
+    orig = getattr(hipops, fname)
+
+    def f(x, *a, **k):
+        label[0] = f"C{x.shape[-1]} @{x.shape[-2]}" if x.dim() == 5 else None
+        try:
+            return orig(x, *a, **k)
+        finally:
+            label[0] = None
+
+    setattr(hipops, fname, f)
+
+
+for fn in ("gn_stats", "gn_apply", "gn_bwd", "add", "concat_channels", "slice_channels", "upsample_nearest", "upsample_nearest_bwd"):
+    wrap_shape(fn)
+
+torch.manual_seed(42)
+net = DiffusionModelUNet(**bench.C4)
+for n, p in net.named_parameters():
+    if float(p.detach().abs().max()) == 0:
+        torch.nn.init.normal_(p, std=0.02)
+net = net.to(dev)
+tr = trainer.DDPMTrainer(net, device=dev)
+shape = (1, 1, size, size, size)
+x0 = bench.synthetic_volume(shape, 42, dev)
+noise = torch.randn(shape, device=dev)
+t = torch.randint(0, 1000, (1,), device=dev)
+for _ in range(2):
+    tr.step(x0, noise, t)
+torch.cuda.synchronize()
+enabled[0] = True
+for _ in range(steps):
+    tr.step(x0, noise, t)
+torch.cuda.synchronize()
+enabled[0] = False
+
+tot = collections.defaultdict(lambda: [0, 0.0])
+for name, lab, e0, e1 in records:
+    k = (name, lab or "")
+    tot[k][0] += 1
+    tot[k][1] += e0.elapsed_time(e1)
+rows = sorted(tot.items(), key=lambda kv: -kv[1][1])
+total = sum(v[1] for v in tot.values()) / steps
+print(f"sum of bracketed calls: {total:.2f} ms/step (eager, includes launch gaps inside a call)")
+by_name = collections.defaultdict(float)
+for (name, lab), (cnt, ms) in rows:
+    by_name[name] += ms / steps
+print("--- by entry point")
+for name, ms in sorted(by_name.items(), key=lambda kv: -kv[1]):
+    print(f"{name:32s} {ms:8.3f} ms/step")
+print("--- by entry point and shape")
+for (name, lab), (cnt, ms) in rows[:90]:
+    print(f"{name:28s} {lab:28s} x{cnt // steps:3d}  {ms / steps:8.3f} ms/step  {ms / cnt * 1e3:9.1f} us/call")
