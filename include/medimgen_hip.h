@@ -78,7 +78,8 @@ int mi_conv_fwd(mi_conv_plan* plan, const void* x, int x_cstride, const float* s
 int mi_conv_dgrad(mi_conv_plan* plan, const void* dy, int dy_cstride, void* dx, int dx_cstride, hipStream_t stream);
 /* dweight += x_act^T * dy   (fp32, torch layout; x_act recomputed from x with the same fused prologue).
  * dy_colsum (optional, fp32, ACCUMULATED): dy_colsum[n*stride + co] += sum over voxels of dy -- the bias / time-embedding
- * gradient, produced from the dY tiles the kernel already holds in LDS */
+ * gradient, produced from the dY fragments the kernel already holds (one all-ones MFMA per k-step); stride 0 sums the whole
+ * batch into one row (= the bias gradient) */
 int mi_conv_wgrad(mi_conv_plan* plan, const void* x, int x_cstride, const float* scale_shift, int silu, const void* dy, int dy_cstride,
                   float* dweight, float* dy_colsum, int dy_colsum_stride, hipStream_t stream);
 /* out[n*out_stride + c] (+)= sum_v x[n][v][c]  (bias / time-embedding gradients) */

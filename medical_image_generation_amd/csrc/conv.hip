@@ -492,10 +492,10 @@ __device__ __forceinline__ void tr_read_async(u32x2& dst, unsigned addr) {
 template <int MAXT>
 struct WgFrags {
   u32x2 a[2];
-  u32x2 b[MAXT][2];
+  u32x2 b[MAXT ? MAXT : 1][2];  // (MAXT = 0: a wave that only accumulates the dY column sums)
 };
 template <int MAXT>
-__device__ __forceinline__ void wg_issue(WgFrags<MAXT>& f, unsigned ya, unsigned xa, const int (&toff)[MAXT], int vox4) {
+__device__ __forceinline__ void wg_issue(WgFrags<MAXT>& f, unsigned ya, unsigned xa, const int (&toff)[MAXT ? MAXT : 1], int vox4) {
   tr_read_async(f.a[0], ya);
   tr_read_async(f.a[1], ya + vox4);
 #pragma unroll
@@ -511,13 +511,19 @@ __device__ __forceinline__ void wg_wait(WgFrags<MAXT>& f) {
   for (int t = 0; t < MAXT; ++t) asm volatile("" : "+v"(f.b[t][0]), "+v"(f.b[t][1]));
   __builtin_amdgcn_sched_barrier(0);
 }
-template <int MAXT>
-__device__ __forceinline__ void wg_mfma(f32x16 (&acc)[MAXT], const WgFrags<MAXT>& f) {
+// CS: this wave also owns the fused bias gradient.  The column sums of dY over the k-step's 16 voxels are one more MFMA of the
+// dY fragment against an all-ones B fragment (every column of the result holds sum_k dY[k][co]) -- no LDS pass, no VALU.
+template <int MAXT, bool CS>
+__device__ __forceinline__ void wg_mfma(f32x16 (&acc)[MAXT ? MAXT : 1], const WgFrags<MAXT>& f, f32x16& cs) {
   u32x4 ra = {f.a[0][0], f.a[0][1], f.a[1][0], f.a[1][1]};
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
     u32x4 rb = {f.b[t][0][0], f.b[t][0][1], f.b[t][1][0], f.b[t][1][1]};
     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra), __builtin_bit_cast(bf16x8, rb), acc[t], 0, 0, 0);
+  }
+  if constexpr (CS) {
+    const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // bf16 1.0 x 8
+    cs = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra), __builtin_bit_cast(bf16x8, ones), cs, 0, 0, 0);
   }
 }
 
@@ -567,9 +573,9 @@ __device__ __forceinline__ void stagey_store(const StageY<NPY>& sy, const Geom& 
 
 // One pass over the tile's 16 k-steps (16 voxels = 2 h-rows x 8 w of one slice) for a wave that owns NTAP taps.
 // Reads of k-step s+1 are in flight under the MFMAs of k-step s (two statically named fragment sets, loop unrolled in pairs).
-template <int NTAP>
-__device__ __forceinline__ void wg_tile(f32x16 (&acc)[NTAP], const int (&toff)[NTAP], const Geom& g, unsigned lds0, unsigned ldy0,
-                                        int kh, int q, int chan_b, int dyrow, int dyslice, int dbg) {
+template <int NTAP, bool CS>
+__device__ __forceinline__ void wg_tile(f32x16 (&acc)[NTAP ? NTAP : 1], const int (&toff)[NTAP ? NTAP : 1], f32x16& cs, const Geom& g,
+                                        unsigned lds0, unsigned ldy0, int kh, int q, int chan_b, int dyrow, int dyslice, int dbg) {
   int sd = 0, sh = 0, sw = 0;
   auto addr_y = [&]() { return ldy0 + sd * dyslice + (sh + kh) * dyrow + (sw + q) * g.vox + chan_b; };
   auto addr_x = [&]() { return lds0 + sd * g.slice + (sh + kh) * g.row + (sw + q) * g.vox + chan_b; };
@@ -587,19 +593,20 @@ __device__ __forceinline__ void wg_tile(f32x16 (&acc)[NTAP], const int (&toff)[N
   for (int s = 0; s < ksteps; s += 2) {
     advance();
     if (dbg != 4) wg_issue<NTAP>(fB, addr_y(), addr_x(), toff, vox4);
-    if (dbg != 3) wg_mfma<NTAP>(acc, fA);
+    if (dbg != 3) wg_mfma<NTAP, CS>(acc, fA, cs);
     if (dbg != 4) wg_wait<NTAP>(fB);
     advance();
     if (s + 2 < ksteps && dbg != 4) wg_issue<NTAP>(fA, addr_y(), addr_x(), toff, vox4);
-    if (dbg != 3) wg_mfma<NTAP>(acc, fB);
+    if (dbg != 3) wg_mfma<NTAP, CS>(acc, fB, cs);
     if (s + 2 < ksteps && dbg != 4) wg_wait<NTAP>(fA);
   }
 }
 
 // 1-tap pairs (1x1 convs): splitting taps over waves would leave 7 of 8 waves idle, so the 16 k-steps are split instead
 // (wave w takes k-steps 2w, 2w+1) and the 8 partial accumulators are folded through LDS once, after the last tile.
-__device__ __forceinline__ void wg_tile_ksplit(f32x16 (&acc)[1], const int (&toff)[1], const Geom& g, unsigned lds0, unsigned ldy0,
-                                               int kh, int q, int chan_b, int dyrow, int dyslice, int wave) {
+template <bool CS>
+__device__ __forceinline__ void wg_tile_ksplit(f32x16 (&acc)[1], const int (&toff)[1], f32x16& cs, const Geom& g, unsigned lds0,
+                                               unsigned ldy0, int kh, int q, int chan_b, int dyrow, int dyslice, int wave) {
   int sd = 0, sh = 0, sw = 0;
   auto advance = [&]() {
     sw += 8;
@@ -615,8 +622,8 @@ __device__ __forceinline__ void wg_tile_ksplit(f32x16 (&acc)[1], const int (&tof
               lds0 + sd * g.slice + (sh + kh) * g.row + (sw + q) * g.vox + chan_b, toff, vox4);
   wg_wait<1>(fA);
   wg_wait<1>(fB);
-  wg_mfma<1>(acc, fA);
-  wg_mfma<1>(acc, fB);
+  wg_mfma<1, CS>(acc, fA, cs);
+  wg_mfma<1, CS>(acc, fB, cs);
 }
 
 // 3-D k3 convs always use the 4x8x8 (+1 halo) tile with 64-byte voxels: row 640, slice 6400 for the x image, 512 / 4096
@@ -638,19 +645,19 @@ __device__ __forceinline__ void wg3_issue(WgFrags<NTAP>& f, unsigned ybase, cons
     tr_read_async_i<OX + 256>(f.b[t][1], xbase[t]);
   }
 }
-template <int S, int NTAP>
-__device__ __forceinline__ void wg3_steps(f32x16 (&acc)[NTAP], WgFrags<NTAP>& fcur, WgFrags<NTAP>& fnext, unsigned ybase,
+template <int S, int NTAP, bool CS>
+__device__ __forceinline__ void wg3_steps(f32x16 (&acc)[NTAP], f32x16& cs, WgFrags<NTAP>& fcur, WgFrags<NTAP>& fnext, unsigned ybase,
                                           const unsigned (&xbase)[NTAP]) {
   if constexpr (S < 16) {
     if constexpr (S + 1 < 16) wg3_issue<S + 1, NTAP>(fnext, ybase, xbase);
-    wg_mfma<NTAP>(acc, fcur);
+    wg_mfma<NTAP, CS>(acc, fcur, cs);
     if constexpr (S + 1 < 16) wg_wait<NTAP>(fnext);
-    wg3_steps<S + 1, NTAP>(acc, fnext, fcur, ybase, xbase);
+    wg3_steps<S + 1, NTAP, CS>(acc, cs, fnext, fcur, ybase, xbase);
   }
 }
-template <int NTAP>
-__device__ __forceinline__ void wg3_tile(f32x16 (&acc)[NTAP], const int (&toff)[NTAP], unsigned lds0, unsigned ldy0, int kh, int q,
-                                         int chan_b) {
+template <int NTAP, bool CS>
+__device__ __forceinline__ void wg3_tile(f32x16 (&acc)[NTAP], const int (&toff)[NTAP], f32x16& cs, unsigned lds0, unsigned ldy0, int kh,
+                                         int q, int chan_b) {
   const unsigned lane_y = ldy0 + kh * WG3_YROW + q * 64 + chan_b;
   unsigned xbase[NTAP];
 #pragma unroll
@@ -658,7 +665,7 @@ __device__ __forceinline__ void wg3_tile(f32x16 (&acc)[NTAP], const int (&toff)[
   WgFrags<NTAP> fA, fB;
   wg3_issue<0, NTAP>(fA, lane_y, xbase);
   wg_wait<NTAP>(fA);
-  wg3_steps<0, NTAP>(acc, fA, fB, lane_y, xbase);
+  wg3_steps<0, NTAP, CS>(acc, cs, fA, fB, lane_y, xbase);
 }
 
 // 512 threads = 8 waves = 2 per SIMD: ds_read_b64_tr_b16 is issue-bound for a lone wave (an 8-byte LDS read needs several
@@ -717,17 +724,33 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
   if (tile >= w.ntiles) return;
   int n, d0, h0, w0;
   tile_origin(g, tile, n, d0, h0, w0);
-  // fused bias-gradient: thread -> (channel cs_co, voxel phase cs_grp); flushed with one atomic per (image, thread)
+  // fused bias / time-embedding gradient (column sums of dY): the workgroup that owns the first cin chunk of its cout block
+  // adds one all-ones MFMA per k-step (wg_mfma<.., CS>).  Tap pairs: wave 7 -- it never has more taps than the others --
+  // keeps the sums in a spare accumulator; 1x1 pairs (k-steps split over the waves): every wave sums its own k-steps.
+  // Flushed with atomics when the image index changes (tiles are visited in increasing order) and at the end.
   const bool do_colsum = w.colsum != nullptr && (pair % a.nchunks) == 0;
-  const int cs_co = threadIdx.x & 31, cs_grp = threadIdx.x >> 5;
-  float cs_acc = 0.f;
-  int cs_n = -1, n_img = n;
+  const bool cs_wave = do_colsum && (ksplit || wave == 7);
+  f32x16& cs = acc[3];  // never a tap accumulator on a column-sum wave (wave 7 owns <= 3 taps; 1x1 pairs use acc[0] only)
+  auto cs_flush = [&](int img) {  // every column of `cs` holds the same sums: lanes 0 / 32 own rows 4h + (e&3) + 8(e>>2)
+    if ((lane & 31) == 0) {
+      const int hh = lane >> 5;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = y * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (co < a.Cout) atomicAdd(w.colsum + (int64_t)img * w.colsum_stride + co, cs[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[e] = 0.f;
+  };
+  int cs_n = n;
   Stage<NP> st;
   StageY<NPY> sy;
   stage_init<NP, NT>(st, g);
   stage_load<NP>(st, a, n, d0, h0, w0, src_c0);
   stagey_load<NPY, NT>(sy, w, y, n, d0, h0, w0);
   bool first = true;
+  int n_img = n;  // image of the tile that is in LDS during the current iteration
   while (true) {
     __syncthreads();  // previous tile fully consumed
     if ((w.dbg != 1 && w.dbg < 3) || first) {
@@ -735,20 +758,14 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
       stagey_store<NPY, NT>(sy, g, ldy);
     }
     __syncthreads();
-    if (do_colsum) {  // this workgroup owns the first cin chunk of its cout block: it also reduces dY over voxels
-      if (n_img != cs_n) {  // image changed (tiles are visited in increasing order): flush
-        if (cs_n >= 0 && y * 32 + cs_co < a.Cout) atomicAdd(w.colsum + (int64_t)cs_n * w.colsum_stride + y * 32 + cs_co, cs_acc);
-        cs_acc = 0.f;
-        cs_n = n_img;
-      }
-      const int nvox = g.TD * g.TH * g.TW;
-      const char* col = ldy + cs_co * 2;
-      for (int v = cs_grp; v < nvox; v += NT / 32) cs_acc += bf2f(*(const bf16*)(col + v * g.vox));
+    if (cs_wave && n_img != cs_n) {  // wave-uniform
+      cs_flush(cs_n);
+      cs_n = n_img;
     }
     const int next = tile + w.nsplit;
     if (next < w.ntiles) {  // next tile's loads fly under this tile's MFMAs
       tile_origin(g, next, n, d0, h0, w0);
-      n_img = n;  // image of the tile that will be in LDS at the next iteration
+      n_img = n;
       if (w.dbg != 1 && w.dbg < 3) {
         stage_load<NP>(st, a, n, d0, h0, w0, src_c0);
         stagey_load<NPY, NT>(sy, w, y, n, d0, h0, w0);
@@ -758,27 +775,35 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
     if (w.dbg != 2) {  // wave-uniform dispatch on this wave's tap count
       f32x16(&a3)[3] = reinterpret_cast<f32x16(&)[3]>(acc);
       const int(&t3)[3] = reinterpret_cast<const int(&)[3]>(toff);
-      if constexpr (GEO3D) {
-        if (nt == 4) wg3_tile<4>(acc, toff, lds0, ldy0, kh, q, chan_b);
-        else if (nt == 3) wg3_tile<3>(a3, t3, lds0, ldy0, kh, q, chan_b);
+      if constexpr (GEO3D) {  // 27 taps: waves 0-2 own 4, waves 3-7 own 3
+        if (nt == 4) wg3_tile<4, false>(acc, toff, cs, lds0, ldy0, kh, q, chan_b);
+        else if (cs_wave) wg3_tile<3, true>(a3, t3, cs, lds0, ldy0, kh, q, chan_b);
+        else wg3_tile<3, false>(a3, t3, cs, lds0, ldy0, kh, q, chan_b);
       } else {
         f32x16(&a2)[2] = reinterpret_cast<f32x16(&)[2]>(acc);
         const int(&t2)[2] = reinterpret_cast<const int(&)[2]>(toff);
         f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
         const int(&t1)[1] = reinterpret_cast<const int(&)[1]>(toff);
-        if (ksplit) wg_tile_ksplit(a1, t1, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, wave);
-        else if (nt == 4) wg_tile<4>(acc, toff, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
-        else if (nt == 3) wg_tile<3>(a3, t3, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
-        else if (nt == 2) wg_tile<2>(a2, t2, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
-        else if (nt == 1) wg_tile<1>(a1, t1, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+        if (ksplit) {
+          if (cs_wave) wg_tile_ksplit<true>(a1, t1, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, wave);
+          else wg_tile_ksplit<false>(a1, t1, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, wave);
+        } else if (cs_wave) {  // wave 7: at most 3 taps (host checks ntaps < 32)
+          if (nt == 3) wg_tile<3, true>(a3, t3, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+          else if (nt == 2) wg_tile<2, true>(a2, t2, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+          else if (nt == 1) wg_tile<1, true>(a1, t1, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+          else wg_tile<0, true>(a1, t1, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+        } else {
+          if (nt == 4) wg_tile<4, false>(acc, toff, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+          else if (nt == 3) wg_tile<3, false>(a3, t3, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+          else if (nt == 2) wg_tile<2, false>(a2, t2, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+          else if (nt == 1) wg_tile<1, false>(a1, t1, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, w.dbg);
+        }
       }
     }
     if (next >= w.ntiles) break;
     tile = next;
   }
-
-  if (do_colsum && cs_n >= 0 && y * 32 + cs_co < a.Cout)
-    atomicAdd(w.colsum + (int64_t)cs_n * w.colsum_stride + y * 32 + cs_co, cs_acc);
+  if (cs_wave) cs_flush(cs_n);
 
   // partial slab: [tap][co 32][ci 32]; D map: col = lane&31 -> ci, row -> co
   float* out = w.part + (int64_t)split * w.split_stride + w.pair_off[pair];
@@ -1273,7 +1298,7 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   static const int dbg = env_int("MI_WGRAD_DBG", 0);
   w.dbg = dbg;
   w.colsum = dy_colsum; w.colsum_stride = dy_colsum_stride;
-  if (dy_colsum && dy_colsum_stride < P->Cout) return MI_ERR_BAD_ARG;
+  if (dy_colsum && dy_colsum_stride != 0 && dy_colsum_stride < P->Cout) return MI_ERR_BAD_ARG;  // 0: one row for the whole batch
   const int hv = a.g.HD * a.g.HH * a.g.HW;
   const int np = (hv * 4 + 255) / 256;
   const int nvox = a.g.TD * a.g.TH * a.g.TW;
@@ -1285,7 +1310,7 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   if (npy > 4 || np > 16) return MI_ERR_BAD_ARG;  // (256-thread counts; the kernel runs 512 threads: half of each)
   int max_taps = 0;
   for (size_t i = 1; i < P->wg.hdr.size(); i += 4) max_taps = P->wg.hdr[i] > max_taps ? P->wg.hdr[i] : max_taps;
-  if (max_taps > 32) return MI_ERR_UNSUPPORTED;
+  if (max_taps >= 32) return MI_ERR_UNSUPPORTED;  // wave 7 keeps a spare accumulator for the fused dY column sums
 #define MI_LAUNCH_WG(NPV) MI_LAUNCH_WG_G(NPV, false)
 #define MI_LAUNCH_WG_G(NPV, G3)                                                                                    \
   do {                                                                                                             \

@@ -113,20 +113,6 @@ class Ctx:
         # algorithmic matmul-class flops of this pass (2*MACs; torch.utils.flop_counter convention)
         self.flops_fwd = 0
         self.flops_bwd = 0
-        # per-conv [N, Cout] fp32 scratch for the fused dy column sums: carved out of ONE buffer that is zeroed by a single
-        # memset when the backward starts (instead of one tiny memset per conv)
-        self._cs_elems = 0
-        self._cs_pool = None
-
-    def cs_reserve(self, nelem):
-        off = self._cs_elems
-        self._cs_elems += (nelem + 3) // 4 * 4
-        return off
-
-    def cs_view(self, off, n, cout, device):
-        if self._cs_pool is None:
-            self._cs_pool = torch.zeros(max(self._cs_elems, 4), dtype=F32, device=device)
-        return self._cs_pool[off:off + n * cout].view(n, cout)
 
     def count(self, fwd_flops, dgrad=True, wgrad=True):
         self.flops_fwd += fwd_flops
@@ -169,7 +155,6 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
     else:
         xin, pn, ps = x, norm, silu
     y = plan.fwd(xin, pn, ps, addvec=av, res=res)
-    cs_off = ctx.cs_reserve(n * cout) if (ctx.tape is not None and d_addvec is None) else -1
     ctx.count(2 * y.numel() * cin * math.prod(kernel), dgrad=need_dx)
     if ctx.tape is not None:
         tape = ctx.tape
@@ -179,12 +164,10 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
             if dy is None:
                 return
             gw = ctx.g(name + ".weight")
-            gb = ctx.g(name + ".bias")
-            # per-image column sums of dy come out of the wgrad kernel (it holds every dY tile in LDS anyway):
-            # they are the time-embedding gradient; the bias gradient is their sum over the batch
-            cs = d_addvec if d_addvec is not None else ctx.cs_view(cs_off, n, cout, dy.device)
-            plan.wgrad(xin, dy, gw, pn, ps, colsum=cs)
-            ops.sum_rows_f32(cs, gb, accumulate=True)
+            # column sums of dy come out of the wgrad kernel (one extra MFMA per k-step on the dY fragments it holds anyway):
+            # per image into `d_addvec` (time-embedding gradient; the caller folds the rows into the bias gradient), or --
+            # row pitch 0 -- summed over the batch straight into the bias gradient
+            plan.wgrad(xin, dy, gw, pn, ps, colsum=d_addvec if d_addvec is not None else ctx.g(name + ".bias"))
             if res is not None:
                 tape.put(res, dy)
             if need_dx:

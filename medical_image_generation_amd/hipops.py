@@ -186,12 +186,17 @@ class ConvPlan:
         return dx
 
     def wgrad(self, x, dy, dweight_f32, st: GNStats | None = None, silu=False, colsum=None):
-        """dweight += wgrad; colsum (optional fp32 [N, Cout] view, row pitch honoured) += per-image column sums of dy."""
+        """dweight += wgrad; colsum (optional fp32) += column sums of dy: an [N, Cout] view (row pitch honoured) receives them
+        per image, a [Cout] vector their sum over the batch (the bias gradient)."""
         assert dweight_f32.dtype == F32 and dweight_f32.is_contiguous()
         cs_stride = 0
         if colsum is not None:
-            assert colsum.dtype == F32 and colsum.shape == (self.n, self.cout) and colsum.stride(1) == 1
-            cs_stride = colsum.stride(0)
+            assert colsum.dtype == F32 and colsum.stride(-1) == 1
+            if colsum.dim() == 2:
+                assert colsum.shape == (self.n, self.cout)
+                cs_stride = colsum.stride(0)
+            else:
+                assert colsum.shape == (self.cout,)
         call("mi_conv_wgrad", self.handle, ptr(x), _cs(x), ptr(st.scale_shift) if st is not None else None, int(silu), ptr(dy), _cs(dy),
              ptr(dweight_f32), ptr(colsum), cs_stride)
 

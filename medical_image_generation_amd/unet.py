@@ -339,6 +339,8 @@ class DiffusionModelUNet(HipModule):
         d_temb_all = torch.zeros_like(temb_all) if grad else None  # conv1 wgrads accumulate their dy column sums here
         if grad:
             def bwd_emb():
+                # d_temb_all holds every conv1's per-image dy column sums: their batch sums are the conv1 bias gradients
+                ops.sum_rows_f32(d_temb_all, a.span([r[0] + ".conv1.conv.bias" for r in self._resnets], a.grad), accumulate=True)
                 d_se = bwd3(d_temb_all)
                 d_emb = ops.silu_bwd_f32(emb, d_se)
                 d_s1 = bwd2(d_emb)

@@ -173,6 +173,9 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     plan.wgrad(xc, gc, dw, colsum=cs)
     check(dw.cpu() - 1, wr.grad, 1e-2, "conv wgrad")
     check(cs.cpu() - 1, g.sum(dim=(2, 3, 4)), 1e-2, "fused dy column sums (bias / temb gradient)")
+    cb = torch.ones(cout, device=dev)  # 1-D target: summed over the batch as well (= the bias gradient)
+    plan.wgrad(xc, gc, torch.zeros_like(w).to(dev), colsum=cb)
+    check(cb.cpu() - 1, g.sum(dim=(0, 2, 3, 4)), 1e-2, "fused bias gradient")
 
 
 def test_conv_fused_prologue_epilogue(ops):
