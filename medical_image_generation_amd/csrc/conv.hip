@@ -32,41 +32,10 @@
 
 #include <vector>
 
-#include "common.h"
+#include "conv_common.h"
 #include "medimgen_hip.h"
 
 namespace {
-
-constexpr int VOXB = 80;    // LDS bytes per voxel (32 ch * 2 B + 16 B pad)
-constexpr int KC = 32;      // channels per chunk
-
-struct Geom {           // tile + LDS geometry (host-computed, passed by value)
-  int TD, TH, TW;       // output tile (voxels); TD * (TH/4) * (TW/8) == 4 * VB
-  int hd, hh, hw;       // halo on each side per axis (0/1)
-  int HD, HH, HW;       // LDS tile dims = T + 2*halo
-  int vox, row, slice;  // byte pitches (voxel: 80 for the b128 fragment reads of fwd/dgrad, 64 for wgrad's transposed reads)
-  int lds_bytes;
-  int tilesD, tilesH, tilesW;
-};
-
-struct ConvArgs {
-  const bf16* x; int x_cs;
-  int N, Di, Hi, Wi, Cin;       // tensor the loader reads (already space-to-depth'ed when strided); Cin = its channel count
-  bf16* y; int y_cs; int Cout;  // channels the kernel produces (store masked to Cout)
-  int ogpq, outc_q;             // output groups (blockIdx.y) per parity class, channels per class (== ny, Cout when no classes)
-  int Do, Ho, Wo;
-  const u32x4* wpk;             // packed A fragments (64 x 16 B each)
-  const int* hdr;               // [ny][nchunks][4] = tap_begin, ntaps, src_c0, wfrag_begin
-  const int* taps;              // LDS byte offsets
-  int nchunks;
-  const float* ss; int ss_C; int pro_silu;  // prologue affine [N][ss_C][2] (channel = src channel % ss_C) or null
-  const float* addvec; int addvec_stride;   // fp32 [Cout] (stride 0) or [N] rows of pitch `stride`; null = none
-  const bf16* res; int res_cs;
-  int ntiles;
-  int dbg;  // ablation knob (MI_IGEMM_DBG): 1 = stage only the first image, 2 = skip the MFMA loop, 3 = skip the epilogue
-  unsigned x_bytes, wpk_bytes;  // sizes for the buffer descriptors (both < 4 GiB, checked on the host)
-  Geom g;
-};
 
 // ------------------------------------------------------------------------------------------------ halo staging
 // Each thread owns NP 16-byte pieces of the halo image: piece pc = tid + 256*i -> LDS voxel pc >> 2, channel part pc & 3.
@@ -95,10 +64,6 @@ __device__ __forceinline__ void stage_init(Stage<NP>& s, const Geom& g) {
 
 // Wave-uniform buffer descriptor (raw, no stride): 32-bit per-lane byte offsets, hardware range check (an offset beyond
 // num_records loads zeros -- which is exactly the conv's zero padding), scalar soffset for wave-uniform displacements.
-typedef __attribute__((ext_vector_type(4))) int i32x4;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
-}
 __device__ __forceinline__ u32x4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
 }
@@ -167,14 +132,6 @@ __device__ __forceinline__ void stage_store(Stage<NP>& s, const ConvArgs& a, int
   }
 }
 
-__device__ __forceinline__ void tile_origin(const Geom& g, int tile, int& n, int& d0, int& h0, int& w0) {
-  int tw = tile % g.tilesW; tile /= g.tilesW;
-  int th = tile % g.tilesH; tile /= g.tilesH;
-  int td = tile % g.tilesD;
-  n = tile / g.tilesD;
-  d0 = td * g.TD; h0 = th * g.TH; w0 = tw * g.TW;
-}
-
 // voxel block b (32 voxels = 4 rows x 8 cols of one slice) -> tile-relative (d, h, w) of its corner
 __device__ __forceinline__ void block_origin(const Geom& g, int b, int& bd, int& bh, int& bw) {
   const int bpw = g.TW / 8, bph = g.TH / 4;
@@ -184,17 +141,6 @@ __device__ __forceinline__ void block_origin(const Geom& g, int b, int& bd, int&
 }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad kernel
-// Persistent: gridDim.x workgroups (about 2 per CU over all cout groups) walk the tiles.  Workgroups that share
-// `blockIdx.x % 8` are observed to share an XCD (speed only), so each of the 8 residue classes owns a CONTIGUOUS tile
-// range: neighbouring tiles, whose halos overlap, are then served by the same L2.
-__device__ __forceinline__ int first_tile(int ntiles, int& last, int& step) {
-  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
-  const int tpx = (ntiles + 7) >> 3;
-  last = (x + 1) * tpx < ntiles ? (x + 1) * tpx : ntiles;
-  step = nslots;
-  return x * tpx + slot;
-}
-
 // LDS reads the compiler may not move or wait for: issue-early / wait-late is placed by hand (cdna guide 5.7, form (ii):
 // the wait statement names every destination "+v", and a sched_barrier keeps the MFMAs on their side of it).
 template <int OFF>
@@ -436,7 +382,7 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {
       for (int cb = 0; cb < NCB; ++cb) {
 #pragma unroll
         for (int grp = 0; grp < 4; ++grp) {
-          const int co = cls_base + ((y - cls * a.ogpq) * NCB + cb) * 32 + grp * 8 + h * 4;
+          const int co = cls_base + ((y - cls * a.ogpq) * NCB + cb) * 32 + (a.perm16 ? h * 16 + grp * 4 : grp * 8 + h * 4);
           if (co >= cls_lim) continue;
           float v[4];
 #pragma unroll
@@ -851,7 +797,11 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
     gid = f * 64 + lane;
   }
   const int* it = items + f * 4;
-  int tap = it[0], co = it[1] + (lane & 31), ci0 = it[2] + (lane >> 5) * 8, tr = it[3] & 1;
+  // flags bit 1 (conv27.hip): MFMA row rho carries output channel 16h + e with rho = (e&3) + 8(e>>2) + 4h, so that a lane's 16
+  // accumulator registers are 16 consecutive channels
+  const int rho = lane & 31;
+  const int crow = (it[3] & 2) ? 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3) : rho;
+  int tap = it[0], co = it[1] + crow, ci0 = it[2] + (lane >> 5) * 8, tr = it[3] & 1;
   F8 v;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -944,6 +894,7 @@ struct mi_conv_plan {
   bf16* d_dxs = nullptr;  // depth image of dx
   bool strided = false;
   bool full27 = false;  // k3 s1 p1 on all three axes: compile-time tap nest
+  bool v27_fwd = false, v27_dg = false;  // forward / data gradient run on conv27.hip (LDS-DMA kernel); weights packed with perm16
 };
 
 namespace {
@@ -972,7 +923,7 @@ int tap_lds_off(const Geom& g, int dd, int dh, int dw) {
 // in channels = InC per parity class qi.  `combos[axis]` lists (q, delta, t); `q_on_input` tells whether q partitions the
 // INPUT channels (fwd on s2d image) or the OUTPUT channels (dgrad producing a depth image).
 void build_tables(Tables& T, const Geom& g, int NCB, const std::vector<AxisCombo> combos[3], const int f[3], const int k[3], bool q_on_input,
-                  int InC, int OutC, bool transposed) {
+                  int InC, int OutC, bool transposed, bool perm16 = false) {
   const int Q = f[0] * f[1] * f[2];
   const int in_chunks_per_q = (InC + KC - 1) / KC;
   const int out_groups_per_q = (OutC + 32 * NCB - 1) / (32 * NCB);
@@ -1002,7 +953,7 @@ void build_tables(Tables& T, const Geom& g, int NCB, const std::vector<AxisCombo
                 T.frag_items.push_back(src_tap);
                 T.frag_items.push_back((cog * NCB + cb) * 32);
                 T.frag_items.push_back(cin0 + ks * 16);
-                T.frag_items.push_back(transposed ? 1 : 0);
+                T.frag_items.push_back((transposed ? 1 : 0) | (perm16 ? 2 : 0));
                 ++nfrag;
               }
             ++nt;
@@ -1133,10 +1084,14 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   P->ncb_dg = Cin > 32 ? 2 : 1;
   // forward: loader reads x (or its depth image: dims Dp.., Q*Cin channels); outputs on the (Do,Ho,Wo) grid
   P->g_fwd = make_geom(2, P->Do, P->Ho, P->Wo, halo_f, N);
-  build_tables(P->fwd, P->g_fwd, P->ncb_fwd, cf, P->f, P->k, true, Cin, Cout, false);
+  static const int use27 = env_int("MI_CONV27", 1);  // 0: keep every conv on the table-driven kernel (A/B runs)
+  const bool geo27 = P->full27 && P->g_fwd.TD == 4 && P->g_fwd.TH == 8 && P->g_fwd.TW == 8;
+  P->v27_fwd = use27 && geo27 && (Cin % 8) == 0;
+  P->v27_dg = use27 && geo27 && (Cout % 8) == 0;
+  build_tables(P->fwd, P->g_fwd, P->ncb_fwd, cf, P->f, P->k, true, Cin, Cout, false, P->v27_fwd);
   // dgrad: loader reads dy (Do,Ho,Wo,Cout); outputs the depth image of dx on the (Dp,Hp,Wp) grid with Q*Cin channels
   P->g_dg = make_geom(2, P->Dp, P->Hp, P->Wp, halo_d, N);
-  build_tables(P->dg, P->g_dg, P->ncb_dg, cdg, P->f, P->k, false, Cout, Cin, true);
+  build_tables(P->dg, P->g_dg, P->ncb_dg, cdg, P->f, P->k, false, Cout, Cin, true, P->v27_dg);
   // wgrad: forward geometry, 32-cout groups
   P->g_wg = make_geom(2, P->Do, P->Ho, P->Wo, halo_f, N, 64);
   build_tables(P->wg, P->g_wg, 1, cf, P->f, P->k, true, Cin, Cout, false);
@@ -1231,6 +1186,15 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
     if (xb >= (1ll << 32)) return MI_ERR_UNSUPPORTED;
     a.x_bytes = (unsigned)xb;
   }
+  a.perm16 = P->v27_fwd;
+  if (P->v27_fwd && !scale_shift) {  // (the fused GroupNorm prologue lives in the register-staged kernel)
+    if (x_cs & 7) return MI_ERR_UNSUPPORTED;
+    const int64_t rb = res ? (int64_t)P->N * P->Do * P->Ho * P->Wo * res_cs * 2 : 0;
+    a.res_bytes = rb < (1ll << 32) ? (unsigned)rb : 0u;
+    const int64_t yb = (int64_t)P->N * P->Do * P->Ho * P->Wo * y_cs * 2;
+    a.y_bytes = yb < (1ll << 32) ? (unsigned)yb : 0u;
+    return mi_launch_conv27(a, P->ncb_fwd, 0, ntiles, P->fwd.ny, st);
+  }
   return launch_igemm_any(a, P->ncb_fwd, P->full27 ? 1 : 0, ntiles, P->fwd.ny, st);
 }
 
@@ -1256,6 +1220,13 @@ int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_c
     int64_t xb = (int64_t)a.N * a.Di * a.Hi * a.Wi * a.x_cs * 2;
     if (xb >= (1ll << 32)) return MI_ERR_UNSUPPORTED;
     a.x_bytes = (unsigned)xb;
+  }
+  a.perm16 = P->v27_dg;
+  if (P->v27_dg) {
+    if (dy_cs & 7) return MI_ERR_UNSUPPORTED;
+    const int64_t yb = (int64_t)P->N * a.Do * a.Ho * a.Wo * a.y_cs * 2;
+    a.y_bytes = yb < (1ll << 32) ? (unsigned)yb : 0u;
+    return mi_launch_conv27(a, P->ncb_dg, 1, ntiles, P->dg.ny, st);
   }
   int e = launch_igemm_any(a, P->ncb_dg, P->full27 ? 2 : 0, ntiles, P->dg.ny, st);
   if (e) return e;

@@ -1,0 +1,71 @@
+// Structures shared by the convolution translation units (conv.hip: plans, table-driven kernel, weight gradient;
+// conv27.hip: the LDS-DMA 3x3x3 stride-1 kernel).  Plain data, passed to kernels by value.
+#pragma once
+#include "common.h"
+
+namespace mi_conv {
+
+constexpr int VOXB = 80;    // LDS bytes per voxel (32 ch * 2 B + 16 B pad)
+constexpr int KC = 32;      // channels per chunk
+
+struct Geom {           // tile + LDS geometry (host-computed, passed by value)
+  int TD, TH, TW;       // output tile (voxels); TD * (TH/4) * (TW/8) == 4 * VB
+  int hd, hh, hw;       // halo on each side per axis (0/1)
+  int HD, HH, HW;       // LDS tile dims = T + 2*halo
+  int vox, row, slice;  // byte pitches (voxel: 80 for the b128 fragment reads of fwd/dgrad, 64 for wgrad's transposed reads)
+  int lds_bytes;
+  int tilesD, tilesH, tilesW;
+};
+
+struct ConvArgs {
+  const bf16* x; int x_cs;
+  int N, Di, Hi, Wi, Cin;       // tensor the loader reads (already space-to-depth'ed when strided); Cin = its channel count
+  bf16* y; int y_cs; int Cout;  // channels the kernel produces (store masked to Cout)
+  int ogpq, outc_q;             // output groups (blockIdx.y) per parity class, channels per class (== ny, Cout when no classes)
+  int Do, Ho, Wo;
+  const u32x4* wpk;             // packed A fragments (64 x 16 B each)
+  const int* hdr;               // [ny][nchunks][4] = tap_begin, ntaps, src_c0, wfrag_begin
+  const int* taps;              // LDS byte offsets
+  int nchunks;
+  const float* ss; int ss_C; int pro_silu;  // prologue affine [N][ss_C][2] (channel = src channel % ss_C) or null
+  const float* addvec; int addvec_stride;   // fp32 [Cout] (stride 0) or [N] rows of pitch `stride`; null = none
+  const bf16* res; int res_cs;
+  unsigned y_bytes;             // size of the output tensor for its buffer descriptor (0: >= 4 GiB)
+  unsigned res_bytes;           // size of the residual tensor for its buffer descriptor (0: >= 4 GiB, element-wise path)
+  int ntiles;
+  int perm16;  // weights packed with the conv27 row permutation (lane's 16 accumulator registers = 16 consecutive channels)
+  int dbg;  // ablation knob (MI_IGEMM_DBG): 1 = stage only the first image, 2 = skip the MFMA loop, 3 = skip the epilogue
+  unsigned x_bytes, wpk_bytes;  // sizes for the buffer descriptors (both < 4 GiB, checked on the host)
+  Geom g;
+};
+
+
+// XCD-aware tile walk of the persistent conv kernels: workgroups that share `blockIdx.x % 8` are observed to share an XCD
+// (speed only), so each of the 8 residue classes owns a CONTIGUOUS tile range -- neighbouring tiles, whose halos overlap,
+// are then served by the same L2.
+static __device__ __forceinline__ int first_tile(int ntiles, int& last, int& step) {
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;
+  last = (x + 1) * tpx < ntiles ? (x + 1) * tpx : ntiles;
+  step = nslots;
+  return x * tpx + slot;
+}
+
+static __device__ __forceinline__ void tile_origin(const Geom& g, int tile, int& n, int& d0, int& h0, int& w0) {
+  int tw = tile % g.tilesW; tile /= g.tilesW;
+  int th = tile % g.tilesH; tile /= g.tilesH;
+  int td = tile % g.tilesD;
+  n = tile / g.tilesD;
+  d0 = td * g.TD; h0 = th * g.TH; w0 = tw * g.TW;
+}
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+}  // namespace mi_conv
+using namespace mi_conv;
+
+// conv27.hip: k3 s1 p1 3-D forward (flip = 0) / data gradient (flip = 1) on the 4x8x8 tile; a.g / tables as for the table-driven kernel
+int mi_launch_conv27(const ConvArgs& a, int NCB, int flip, int ntiles, int ny, hipStream_t st);
