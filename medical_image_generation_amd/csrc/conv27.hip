@@ -1,26 +1,34 @@
-// 3x3x3 stride-1 convolution (forward and data gradient) for gfx950: one persistent workgroup per CU, both MFMA operands
-// served from LDS that is filled by LDS-DMA (buffer_load ... lds) -- no staging registers, no per-wave weight fetches.
+// 3x3x3 stride-1 convolution (forward and data gradient) for gfx950: one persistent 8-wave workgroup per CU with fixed
+// wave roles; both MFMA operands are served from LDS that is filled by LDS-DMA (buffer_load ... lds).
 // (Same call sites as conv.hip: every k3 s1 p1 `Convolution` of UNet:630-672,557-565,1935 / AEKL:158-187.)
 //
 // Why a second kernel.  In the table-driven kernel (conv.hip) every wave fetches its own copy of every weight fragment
 // from L2 (0.5 KiB per MFMA: at full MFMA rate that alone is the CU's whole 64 B/clk vector-memory path), the halo image
 // goes through 40 VGPRs + ds_write, and the epilogue stores 8 bytes per lane at a voxel stride (16 valid bytes per
-// 128-byte line per instruction).  Here:
-//   * A (weights): packed fragments are 1 KiB each and lane-linear, i.e. exactly one LDS-DMA wave-instruction.  The four
-//     waves share them through an LDS ring of tap groups; a group is requested P groups ahead and is checked (counted
-//     vmcnt + s_barrier) ONE group before its first use, so the fragment prefetch runs across group boundaries.
-//     Single-chunk 32-channel layers keep all 27 taps resident (nothing is re-fetched after the first tile).
-//   * B (activations): the halo image 6x10x10 voxels x 32 channels is dense (64-byte voxels, 38.4 KB) and double
-//     buffered; it is filled by LDS-DMA with the hardware range check supplying the zero padding.  Bank conflicts of the
-//     4x8-voxel ds_read_b128 fragment reads are removed by an XOR swizzle of the 16-byte slot with the halo row
-//     (slot ^= hh & 3), applied on the DMA's per-lane SOURCE address (the LDS destination of a DMA is lane-linear).
-//   * Epilogue: accumulators -> fp32 staging tile in LDS (wave-private) -> read back as 8 channels per lane so that four
-//     consecutive lanes cover a voxel's 64 bytes and 32 lanes cover 8 voxels along W: full-line 16-byte stores; bias /
-//     time-embedding and the residual are added in fp32 on the way (one rounding, residual read with the same full lines).
-//   * Output channels are assigned to MFMA rows so that a lane's 16 accumulator registers are 16 CONSECUTIVE channels
-//     (row (e&3) + 8(e>>2) + 4h <-> channel 16h + e; the permutation is applied when the weights are packed).
-// All vector-memory operations of the main loop are issued in program order and waited for with counted vmcnt: a wait
-// constant may only be too SMALL (stricter) when other operations (epilogue loads / stores) are in flight, never too large.
+// 128-byte line per instruction; with bias rows + residual it costs as much as the MFMAs).  Measured on MI355X, a
+// 4-wave version of this design whose waves issued their own DMA and ran their own epilogue spent 20 % of its time
+// issuing LDS-DMA and 13 % in the epilogue while the bare fragment-read + MFMA stream ran at 1.3-1.45 PFLOP/s: hence roles.
+//
+//   waves 0-3  COMPUTE: one per SIMD; wave w owns the d-slice w of the 4x8x8-voxel tile (two 4x8 voxel blocks) and NCB
+//              32-channel output blocks.  Their instruction stream is: counted lgkmcnt, MFMA, one ds_read_b128 of the NEXT
+//              tap's fragments -- a steady LDS trickle (1 KiB per MFMA slot per wave) instead of bursts.  At tile end the
+//              accumulators go to a bf16 staging tile in LDS and are re-initialised with bias (+ time embedding).
+//   waves 4-5  WEIGHT LOADERS: packed A fragments are 1 KiB and lane-linear = exactly one LDS-DMA instruction; a ring of
+//              3 tap groups is shared by the compute waves, group J+2 is requested while group J is consumed and checked
+//              (vmcnt(0) + s_barrier) one group before its first use, so fragment prefetch runs across group boundaries.
+//              Single-chunk 32-channel layers keep all 27 taps resident: nothing is re-fetched after the first tile.
+//   waves 6-7  HALO LOADERS + STORE EPILOGUE: the halo image 6x10x10 voxels x 32 channels is dense (64-byte voxels,
+//              38.4 KB), double buffered, filled by LDS-DMA with the hardware range check supplying the zero padding; bank
+//              conflicts of the 4x8-voxel fragment reads are removed by XOR-ing the 16-byte slot with the halo row
+//              (slot ^= hh & 3) on the DMA's per-lane SOURCE address (the LDS destination of a DMA is lane-linear).
+//              They also turn the previous tile's staging tile into full-line 16-byte stores (+ residual), a few pieces
+//              per tap group, so the compute waves never wait for global memory.
+// Every wave executes the same number of s_barrier (one per tap group + prologue + final); loaders wait for their own DMA
+// with vmcnt before the barrier that publishes it (LDS-DMA data is ordered for another wave's ds_read only that way).
+// Output channels are assigned to MFMA rows so that a lane's 16 accumulator registers are 16 CONSECUTIVE channels
+// (row (e&3) + 8(e>>2) + 4h <-> channel 16h + e; the permutation is applied when the weights are packed).
+// Rounding: conv + bias/temb is rounded to bf16 once (staging), the residual is added to that and rounded again -- the
+// same two roundings as the reference's autocast path (conv output in bf16, then `skip + h`, UNet:701).
 #include <stdlib.h>
 
 #include "conv_common.h"
@@ -31,16 +39,28 @@ namespace {
 constexpr int HROW = 640, HSLICE = 6400;   // dense halo image: 10 voxels x 64 B per row, 10 rows per slice, 6 slices
 constexpr int HALO_VOX = 600;
 constexpr int HALO_BYTES = 40960;          // image (38400 B) rounded up to 40 whole 1-KiB DMA pieces
-constexpr int HP = 10;                     // halo pieces per wave and image
-constexpr int EPI_PITCH = 144;             // staging: 32 fp32 channels per voxel + 16 B (conflict-free b128 writes)
-constexpr int EPI_WAVE = 32 * EPI_PITCH;   // one 32-voxel block per pass
-constexpr int RES_OPS = 8;                 // residual prefetch: at most VB * NCB * 2 loads per lane
+constexpr int HPW = 20;                    // halo pieces per halo-loader wave and image
+constexpr int RD = 3;                      // ring slots: weight groups are requested 2 groups ahead
 
 template <int NCB> struct Cfg;
-template <> struct Cfg<1> { static constexpr int GT = 9, P = 2; };  // 3 groups of 9 taps, whole chunk resident in the ring
-template <> struct Cfg<2> { static constexpr int GT = 3, P = 3; };  // 9 groups of 3 taps, ring of 4
+template <> struct Cfg<1> { static constexpr int GT = 9; };  // 3 groups of 9 taps: the ring holds a whole chunk
+template <> struct Cfg<2> { static constexpr int GT = 3; };  // 9 groups of 3 taps
 
 typedef __attribute__((address_space(3))) void lds_void;
+
+template <int NCB>
+struct K {
+  static constexpr int GT = Cfg<NCB>::GT, NG = 27 / GT;
+  static constexpr int FRAGS = GT * 2 * NCB, GROUP_BYTES = FRAGS * 1024, RING = RD * GROUP_BYTES;
+  static constexpr int VOXP = NCB * 64;        // staging bytes per voxel (bf16), 16-byte slots XOR-swizzled with the voxel index
+  static constexpr int PV = NCB * 4;           // 16-byte pieces per voxel
+  static constexpr int STG_WAVE = 64 * VOXP;   // one compute wave's 64 voxels
+  static constexpr int RING0 = 2 * HALO_BYTES, STG0 = RING0 + RING, AV0 = STG0 + 4 * STG_WAVE;
+  static constexpr int AV_WAVE = NCB * 2 * 64;  // per compute wave: bias (+ time embedding) of its accumulator channels [cb][h][16] fp32
+  static constexpr int LDS_TOTAL = AV0 + 4 * AV_WAVE;
+  static constexpr int PIECES = 2 * PV;        // store-epilogue pieces per lane of a halo wave (2 slices x 64 voxels x PV / 64 lanes)
+  static constexpr int PPT = (PIECES + NG - 2) / (NG - 1);  // ... processed per tap group
+};
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
@@ -77,7 +97,7 @@ __device__ __forceinline__ void issue_one(Frags<NCB>& f, const unsigned (&bb)[2]
   constexpr int TH = (U / 3) % 3;
   constexpr int BOFF = (U / 9) * HSLICE + TH * HROW + (U % 3) * 64;
   constexpr int t = T % Cfg<NCB>::GT;
-  constexpr int HALF = 2 + NCB;      // reads per k-step
+  constexpr int HALF = 2 + NCB;  // reads per k-step
   constexpr int ks = Q / HALF, q = Q % HALF;
   if constexpr (NCB == 2) {
     if constexpr (q == 0) lds_read16<BOFF>(f.b[ks][0], bb[0][TH][ks]);
@@ -97,38 +117,37 @@ __device__ __forceinline__ void issue_frags(Frags<NCB>& f, const unsigned (&bb)[
   if constexpr (NCB == 2) { issue_one<6, T, NCB, FLIP>(f, bb, ab); issue_one<7, T, NCB, FLIP>(f, bb, ab); }
 }
 
-// One tap = 4*NCB MFMAs, each followed by its share of the NEXT tap's fragment reads (1 per MFMA; 2,2,1,1 for NCB = 1): the LDS
-// sees a steady trickle instead of a burst, and with one wave per SIMD the reads' latency hides under the following MFMAs.
+// One tap = 4*NCB MFMAs, each followed by its share of the NEXT tap's fragment reads (1 per MFMA; 2,2,1,1 for NCB = 1).
 // LDS returns in order, so before MFMA k a COUNTED lgkmcnt suffices: (reads of this tap not needed yet) + (reads of the next tap
 // already issued).  The wait names the MFMA's operands ("+v") and a sched_barrier pins the order (cdna guide 5.7 (ii), rule 18).
-template <int K, int NCB>
+template <int KI, int NCB>
 __device__ __forceinline__ void wait_operands(Frags<NCB>& f) {
   if constexpr (NCB == 2) {
-    constexpr int ks = K / 4, vb = (K / 2) % 2, cb = K % 2;
-    constexpr int N = (K == 3 || K == 7) ? 7 : 6;
+    constexpr int ks = KI / 4, vb = (KI / 2) % 2, cb = KI % 2;
+    constexpr int N = (KI == 3 || KI == 7) ? 7 : 6;
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.a[ks][cb]), "+v"(f.b[ks][vb]) : "i"(N));
   } else {
-    constexpr int ks = K / 2, vb = K % 2;
-    constexpr int N = K == 0 ? 4 : 5;
+    constexpr int ks = KI / 2, vb = KI % 2;
+    constexpr int N = KI == 0 ? 4 : 5;
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.a[ks][0]), "+v"(f.b[ks][vb]) : "i"(N));
   }
   __builtin_amdgcn_sched_barrier(0);
 }
-template <int K, int TN, int NCB, int FLIP>
+template <int KI, int TN, int NCB, int FLIP>
 __device__ __forceinline__ void mfma_step(f32x16 (&acc)[2][NCB], Frags<NCB>& cur, Frags<NCB>& nxt, const unsigned (&bb)[2][3][2], unsigned ab) {
-  wait_operands<K, NCB>(cur);
+  wait_operands<KI, NCB>(cur);
   if constexpr (NCB == 2) {
-    constexpr int ks = K / 4, vb = (K / 2) % 2, cb = K % 2;
+    constexpr int ks = KI / 4, vb = (KI / 2) % 2, cb = KI % 2;
     acc[vb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a[ks][cb]), __builtin_bit_cast(bf16x8, cur.b[ks][vb]),
-                                                            acc[vb][cb], 0, 0, 0);
-    issue_one<K, TN, NCB, FLIP>(nxt, bb, ab);
+                                                          acc[vb][cb], 0, 0, 0);
+    issue_one<KI, TN, NCB, FLIP>(nxt, bb, ab);
   } else {
-    constexpr int ks = K / 2, vb = K % 2;
+    constexpr int ks = KI / 2, vb = KI % 2;
     acc[vb][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur.a[ks][0]), __builtin_bit_cast(bf16x8, cur.b[ks][vb]),
-                                                           acc[vb][0], 0, 0, 0);
-    if constexpr (K == 0) { issue_one<0, TN, NCB, FLIP>(nxt, bb, ab); issue_one<1, TN, NCB, FLIP>(nxt, bb, ab); }
-    else if constexpr (K == 1) { issue_one<2, TN, NCB, FLIP>(nxt, bb, ab); issue_one<3, TN, NCB, FLIP>(nxt, bb, ab); }
-    else if constexpr (K == 2) issue_one<4, TN, NCB, FLIP>(nxt, bb, ab);
+                                                         acc[vb][0], 0, 0, 0);
+    if constexpr (KI == 0) { issue_one<0, TN, NCB, FLIP>(nxt, bb, ab); issue_one<1, TN, NCB, FLIP>(nxt, bb, ab); }
+    else if constexpr (KI == 1) { issue_one<2, TN, NCB, FLIP>(nxt, bb, ab); issue_one<3, TN, NCB, FLIP>(nxt, bb, ab); }
+    else if constexpr (KI == 2) issue_one<4, TN, NCB, FLIP>(nxt, bb, ab);
     else issue_one<5, TN, NCB, FLIP>(nxt, bb, ab);
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -148,241 +167,117 @@ __device__ __forceinline__ void tap_body(f32x16 (&acc)[2][NCB], Frags<NCB>& cur,
   }
 }
 
+// ------------------------------------------------------------------------------------------------ image sequence
+// An "image" = one 32-channel chunk of one tile.  Every wave walks the same sequence (wave-uniform scalars).
+struct Seq {
+  int tile, ch, n, d0, h0, w0;          // current image
+  int ntile, nch, nn, nd0, nh0, nw0;    // next image (ntile < 0: none)
+};
+__device__ __forceinline__ void seq_next(Seq& q, const ConvArgs& a, int tile_step, int tile_last) {
+  if (q.ch + 1 < a.nchunks) { q.ntile = q.tile; q.nch = q.ch + 1; q.nn = q.n; q.nd0 = q.d0; q.nh0 = q.h0; q.nw0 = q.w0; }
+  else if (q.tile + tile_step < tile_last) { q.ntile = q.tile + tile_step; q.nch = 0; tile_origin(a.g, q.ntile, q.nn, q.nd0, q.nh0, q.nw0); }
+  else { q.ntile = -1; q.nch = 0; q.nn = q.nd0 = q.nh0 = q.nw0 = 0; }
+}
+__device__ __forceinline__ void seq_advance(Seq& q) {
+  q.tile = q.ntile; q.ch = q.nch; q.n = q.nn; q.d0 = q.nd0; q.h0 = q.nh0; q.w0 = q.nw0;
+}
+
+// ------------------------------------------------------------------------------------------------ compute waves
 template <int NCB>
-struct State {
+struct CState {
   f32x16 acc[2][NCB];
   Frags<NCB> fr[2];
-  unsigned lanebase[2][3][2];  // halo fragment-read bases relative to a buffer
-  unsigned bcur[2][3][2];      // ... inside the buffer of the image being consumed
+  unsigned bcur[2][3][2];      // halo fragment-read lane bases inside the buffer of the image being consumed
   unsigned abase, abase_next;  // A fragment-read bases: ring slot of the current / the next group
-  int hp[HP];                  // this lane's halo DMA pieces: (slot << 24) | (hd << 16) | (hh << 8) | hw, or -1
-  // wave-uniform
+  int av_n;                    // image index the LDS bias table of this wave was loaded for
   int cur;                     // halo buffer of the current image
-  int slot;                    // ring slot of the current group
-  int a_ch, a_j;               // stream position (chunk, group) of the next weight group to request
-  int tile, ch, n, d0, h0, w0; // current image
-  int ntile, nch, nn, nd0, nh0, nw0;  // next image (ntile < 0: none)
-  int res_pending;             // residual prefetch in flight (changes the vmcnt constants of the last groups)
-  int st_pending;              // the previous tile's output stores (a fixed number) may still be in flight at the first group tops
-  int av_n;                    // image index the bias / time-embedding registers were loaded for
-  float av[NCB][8];            // addvec of this lane's 8 read-back channels per cout block
-  u32x4 resv[2][NCB][2];       // prefetched residual pieces [vb][cb][i]
+  int slot;                    // ring slot of the previous group
 };
 
-template <int NCB>
-struct K {
-  using C = Cfg<NCB>;
-  static constexpr int GT = C::GT, P = C::P, NG = 27 / GT, RD = P + 1;
-  static constexpr int FRAGS = GT * 2 * NCB, DA = (FRAGS + 3) / 4, GROUP_BYTES = FRAGS * 1024, RING = RD * GROUP_BYTES;
-  static constexpr int RING0 = 2 * HALO_BYTES, EPI0 = RING0 + RING, LDS_TOTAL = EPI0 + 4 * EPI_WAVE;
-};
-
-// one weight group -> ring slot `slot` (this wave's share: fragments wave, wave + 4, ...; the tail repeats the last fragment so
-// that every wave issues exactly DA operations)
-template <int NCB>
-__device__ __forceinline__ void issue_A(const ConvArgs& a, char* lds, int y, int wave, int lane, int ch, int j, int slot) {
-  using KK = K<NCB>;
-  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpk, a.wpk_bytes);
-  // fragments are packed [cout group][chunk][tap][ks][cb] and every chunk of a k3 s1 conv has all 27 taps: no table lookup
-  // (a load inside the loop would be a VECTOR load -- the kernel stores to global memory -- and drain the DMA queue)
-  const int wfrag = (y * a.nchunks + ch) * (27 * 2 * NCB) + j * KK::FRAGS;
-#pragma unroll
-  for (int i = 0; i < KK::DA; ++i) {
-    int f = wave + 4 * i;
-    f = f < KK::FRAGS ? f : KK::FRAGS - 1;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + KK::RING0 + slot * KK::GROUP_BYTES + f * 1024), 16, lane * 16,
-                                             (wfrag + f) * 1024, 0, 0);
-  }
-}
-
-// halo image of (n, d0, h0, w0), channels [src_c0, src_c0 + 32) -> buffer `buf`; valid == 0 zero-fills (keeps the count exact)
-template <int NCB>
-__device__ __forceinline__ void issue_halo(const ConvArgs& a, char* lds, const int (&hp)[HP], int wave, int buf, int valid, int n, int d0,
-                                           int h0, int w0, int src_c0) {
-  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
-#pragma unroll
-  for (int k = 0; k < HP; ++k) {
-    const int pk = hp[k];
-    const int gd = d0 - 1 + ((pk >> 16) & 255), gh = h0 - 1 + ((pk >> 8) & 255), gw = w0 - 1 + (pk & 255);
-    const int c = src_c0 + ((pk >> 24) & 3) * 8;
-    const bool ok = (valid != 0) & (pk >= 0) & ((unsigned)gd < (unsigned)a.Di) & ((unsigned)gh < (unsigned)a.Hi) & ((unsigned)gw < (unsigned)a.Wi) &
-                    (c + 8 <= a.Cin);  // (bitwise: one select, no branches)
-    const unsigned off = ok ? (unsigned)((((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.x_cs + c) * 2u : 0xfffffff0u;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(lds + buf * HALO_BYTES + (wave + 4 * k) * 1024), 16, off, 0, 0, 0);
-  }
-}
-
-template <int NCB>
-__device__ __forceinline__ void mfmas(f32x16 (&acc)[2][NCB], const Frags<NCB>& f) {
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-    for (int vb = 0; vb < 2; ++vb)
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-        acc[vb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[ks][cb]), __builtin_bit_cast(bf16x8, f.b[ks][vb]),
-                                                              acc[vb][cb], 0, 0, 0);
-}
-
-// Top of group J of the current image: the NEXT group's weights (and, at the last group, the next image's halo) must have
-// landed in every wave's view; then the slot of the previous group is refilled P groups ahead.
 template <int J, int NCB>
-__device__ __forceinline__ void group_top(State<NCB>& s, const ConvArgs& a, char* lds, int y, int wave, int lane) {
+__device__ __forceinline__ void compute_top(CState<NCB>& s, int lane) {
   using KK = K<NCB>;
-  constexpr int X = (KK::P - 2) * KK::DA + ((J >= 1 && J <= KK::P - 1) ? HP : 0);
-  constexpr int ST_OPS = 4 * NCB;  // output stores per lane and tile (epilogue, vector path)
-  if (!(a.dbg & 2)) {
-    if (s.res_pending) wait_vm<X + RES_OPS>();
-    else if (J <= KK::P - 2 && s.st_pending) wait_vm<X + ST_OPS>();  // DMA_A(J+1) is older than those stores: they may stay in flight
-    else wait_vm<X>();
-  }
-  if constexpr (J == KK::P - 2) s.st_pending = 0;
-  if (!(a.dbg & 8)) __builtin_amdgcn_s_barrier();
-  // on entry s.slot is the ring slot of group J-1: every wave is done with it, and (ring depth = P + 1) it is the slot of group J+P
-  if (!(a.dbg & 32)) issue_A<NCB>(a, lds, y, wave, lane, s.a_ch, s.a_j, s.slot);
-  if (++s.a_j == KK::NG) { s.a_j = 0; s.a_ch = s.a_ch + 1 == a.nchunks ? 0 : s.a_ch + 1; }
-  if constexpr (J == 0) {
-    if (!(a.dbg & 16)) issue_halo<NCB>(a, lds, s.hp, wave, s.cur ^ 1, s.ntile >= 0, s.nn, s.nd0, s.nh0, s.nw0, s.nch * 32);
-  }
-  const int sj = s.slot + 1 == KK::RD ? 0 : s.slot + 1;  // slot of group J
-  const int sj1 = sj + 1 == KK::RD ? 0 : sj + 1;         // slot of group J+1 (checked by THIS top: its fragments may be prefetched)
+  __builtin_amdgcn_s_barrier();  // group J+1's weights (and, at the last group, the next image's halo) are in LDS for every wave
+  const int sj = s.slot + 1 == RD ? 0 : s.slot + 1;  // slot of group J
+  const int sj1 = sj + 1 == RD ? 0 : sj + 1;         // slot of group J+1
   s.abase = KK::RING0 + sj * KK::GROUP_BYTES + lane * 16;
   s.abase_next = KK::RING0 + sj1 * KK::GROUP_BYTES + lane * 16;
   s.slot = sj;
 }
 
-// residual of the current tile in the read-back layout (8 channels = 16 bytes per lane: full lines), prefetched during the last
-// chunk; consumed by the epilogue
-template <int NCB>
-__device__ __forceinline__ void issue_res(State<NCB>& s, const ConvArgs& a, int y, int wave, int lane) {
-  const int piece = lane & 3;
-  const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res_bytes);
-#pragma unroll
-  for (int vb = 0; vb < 2; ++vb)
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int v = i * 16 + (lane >> 2);
-        const int od = s.d0 + wave, oh = s.h0 + vb * 4 + (v >> 3), ow = s.w0 + (v & 7);
-        const int co = (y * NCB + cb) * 32 + piece * 8;
-        const bool ok = (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co + 8 <= a.Cout);
-        const unsigned off = ok ? (unsigned)(((((int64_t)(s.n * a.Do + od) * a.Ho + oh) * a.Wo + ow) * a.res_cs + co) * 2) : 0xfffffff0u;
-        const u32x4 z = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0));  // out of range -> 0
-        s.resv[vb][cb][i] = z;
-      }
-}
-
 template <int T, int PAR, int NCB, int FLIP>
-__device__ __forceinline__ void taps(State<NCB>& s, const ConvArgs& a, char* lds, int y, int wave, int lane, bool fast_res) {
+__device__ __forceinline__ void taps(CState<NCB>& s, int lane) {
   using KK = K<NCB>;
   if constexpr (T < 27) {
     constexpr int cur = (T + PAR) & 1;
-    if constexpr (T % KK::GT == 0) group_top<T / KK::GT, NCB>(s, a, lds, y, wave, lane);
-    if constexpr (T == 18) {
-      if (fast_res && s.ch == a.nchunks - 1) {  // wave-uniform
-        issue_res<NCB>(s, a, y, wave, lane);
-        s.res_pending = (KK::GT == 3);  // (GT = 9: no group top follows inside this image); RES_OPS == 2 * 2 * 2 loads
-      }
-    }
+    if constexpr (T % KK::GT == 0) compute_top<T / KK::GT, NCB>(s, lane);
     if constexpr (T + 1 < 27) {
       tap_body<T + 1, NCB, FLIP>(s.acc, s.fr[cur], s.fr[cur ^ 1], s.bcur, (T + 1) % KK::GT == 0 ? s.abase_next : s.abase);
     } else {  // next: first tap of the next image -- other halo buffer, next group's slot
-      const unsigned boff = (s.cur ^ 1) * HALO_BYTES;
+      const unsigned delta = s.cur ? 0u - (unsigned)HALO_BYTES : (unsigned)HALO_BYTES;
 #pragma unroll
       for (int vb = 0; vb < 2; ++vb)
 #pragma unroll
         for (int th = 0; th < 3; ++th)
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) s.bcur[vb][th][ks] = s.lanebase[vb][th][ks] + boff;
+          for (int ks = 0; ks < 2; ++ks) s.bcur[vb][th][ks] += delta;
       tap_body<0, NCB, FLIP>(s.acc, s.fr[cur], s.fr[cur ^ 1], s.bcur, s.abase_next);
     }
-    taps<T + 1, PAR, NCB, FLIP>(s, a, lds, y, wave, lane, fast_res);
+    taps<T + 1, PAR, NCB, FLIP>(s, lane);
   }
 }
 
+// bias (+ time embedding) table of this wave in LDS: [cb][h][16] fp32; the accumulators start from it (the MFMA adds on top)
 template <int NCB>
-__device__ __forceinline__ void epilogue(State<NCB>& s, const ConvArgs& a, char* lds, int y, int wave, int lane, bool fast_res) {
+__device__ __forceinline__ void load_av(CState<NCB>& s, const ConvArgs& a, char* lds, int y, int wave, int lane, int n) {
   using KK = K<NCB>;
-  const int r = lane & 31, h = lane >> 5, piece = lane & 3;
-  char* stg = lds + KK::EPI0 + wave * EPI_WAVE;
-  const bool vec_ok = (a.y_cs & 7) == 0 && (a.Cout & 7) == 0 && a.y_bytes != 0;  // wave-uniform
-  if (a.addvec && s.av_n != s.n) {  // wave-uniform; the image index changes once in thousands of tiles
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int co = (y * NCB + cb) * 32 + piece * 8 + j;
-        s.av[cb][j] = co < a.Cout ? a.addvec[(int64_t)s.n * a.addvec_stride + co] : 0.f;
-      }
-    s.av_n = s.n;
+  float* tab = (float*)(lds + KK::AV0 + wave * KK::AV_WAVE);
+  for (int i = lane; i < NCB * 32; i += 64) {  // i = cb*32 + 16h + e  == channel offset inside this workgroup's cout range
+    const int co = y * NCB * 32 + i;
+    tab[i] = (a.addvec && co < a.Cout) ? a.addvec[(int64_t)n * a.addvec_stride + co] : 0.f;
   }
-  const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y, a.y_bytes);
+  s.av_n = n;
+}
+template <int NCB>
+__device__ __forceinline__ void init_acc(CState<NCB>& s, char* lds, int wave, int lane) {
+  using KK = K<NCB>;
+  const float* tab = (const float*)(lds + KK::AV0 + wave * KK::AV_WAVE) + 16 * (lane >> 5);
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *(const f32x4*)(tab + cb * 32 + 4 * q);
+#pragma unroll
+      for (int vb = 0; vb < 2; ++vb)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s.acc[vb][cb][4 * q + e] = v[e];
+    }
+}
+
+// accumulators -> bf16 staging tile of this wave: voxel v = vb*32 + r, channels cb*32 + 16h + (0..15) = slots cb*4 + 2h, +1
+template <int NCB>
+__device__ __forceinline__ void stage_acc(CState<NCB>& s, char* lds, int wave, int lane) {
+  using KK = K<NCB>;
+  const int r = lane & 31, h = lane >> 5;
+  char* stg = lds + KK::STG0 + wave * KK::STG_WAVE;
 #pragma unroll
   for (int vb = 0; vb < 2; ++vb)
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
-      float* wp = (float*)(stg + r * EPI_PITCH + h * 64);
+      const int v = vb * 32 + r;
+      F8 lo, hi;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 v = {s.acc[vb][cb][4 * q], s.acc[vb][cb][4 * q + 1], s.acc[vb][cb][4 * q + 2], s.acc[vb][cb][4 * q + 3]};
-        *(f32x4*)(wp + 4 * q) = v;
-      }
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s.acc[vb][cb][e] = 0.f;
-      const int co = (y * NCB + cb) * 32 + piece * 8;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int v = i * 16 + (lane >> 2);
-        const float* rp = (const float*)(stg + v * EPI_PITCH + piece * 32);
-        f32x4 lo = *(const f32x4*)rp, hi = *(const f32x4*)(rp + 4);
-        F8 f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { f.v[j] = lo[j] + s.av[cb][j]; f.v[4 + j] = hi[j] + s.av[cb][4 + j]; }
-        const int od = s.d0 + wave, oh = s.h0 + vb * 4 + (v >> 3), ow = s.w0 + (v & 7);
-        const bool inside = (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co < a.Cout);
-        const int64_t vox = ((int64_t)(s.n * a.Do + od) * a.Ho + oh) * a.Wo + ow;
-        if (a.res) {
-          if (fast_res) {
-            F8 rr = unpack8(s.resv[vb][cb][i]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) f.v[j] += rr.v[j];
-          } else if (inside) {
-            const bf16* rq = a.res + vox * a.res_cs + co;
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (co + j < a.Cout) f.v[j] += bf2f(rq[j]);
-          }
-        }
-        if (vec_ok) {  // always issued (masked lanes get an out-of-range offset): the store count is part of the vmcnt bookkeeping
-          const unsigned off = inside ? (unsigned)((vox * a.y_cs + co) * 2) : 0xfffffff0u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, pack8(f)), ry, (int)off, 0, 0);
-        } else if (inside) {
-          bf16* yp = a.y + vox * a.y_cs + co;
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (co + j < a.Cout) yp[j] = f2bf(f.v[j]);
-        }
-      }
+      for (int e = 0; e < 8; ++e) { lo.v[e] = s.acc[vb][cb][e]; hi.v[e] = s.acc[vb][cb][8 + e]; }
+      const int s0 = cb * 4 + 2 * h, sw = v & (KK::PV - 1);
+      *(u32x4*)(stg + v * KK::VOXP + ((s0 ^ sw) * 16)) = pack8(lo);
+      *(u32x4*)(stg + v * KK::VOXP + (((s0 + 1) ^ sw) * 16)) = pack8(hi);
     }
-  s.res_pending = 0;
-  s.st_pending = vec_ok;
 }
 
 template <int NCB, int FLIP>
-__global__ void __launch_bounds__(256, 1) k_conv27(ConvArgs a) {
-  using KK = K<NCB>;
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int y = blockIdx.y;
-  int tile_last, tile_step;
-  const int tile0 = first_tile(a.ntiles, tile_last, tile_step);
-  if (tile0 >= tile_last) return;  // whole workgroup, before any barrier
-  const Geom& g = a.g;
-  const bool fast_res = a.res != nullptr && (a.res_cs & 7) == 0 && a.res_bytes != 0;  // wave-uniform
-
-  State<NCB> s;
-  {  // lane constants
+__device__ __forceinline__ void compute_role(const ConvArgs& a, char* lds, int y, int wave, int lane, int tile0, int tile_step, int tile_last) {
+  CState<NCB> s;
+  {
     const int r = lane & 31, h = lane >> 5, row = r >> 3, col = r & 7;
 #pragma unroll
     for (int vb = 0; vb < 2; ++vb)
@@ -390,59 +285,253 @@ __global__ void __launch_bounds__(256, 1) k_conv27(ConvArgs a) {
       for (int th = 0; th < 3; ++th)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-          s.lanebase[vb][th][ks] = wave * HSLICE + (vb * 4 + row) * HROW + col * 64 + (((ks * 2 + h) ^ ((row + th) & 3)) * 16);
-          s.bcur[vb][th][ks] = s.lanebase[vb][th][ks];
+          s.bcur[vb][th][ks] = wave * HSLICE + (vb * 4 + row) * HROW + col * 64 + (((ks * 2 + h) ^ ((row + th) & 3)) * 16);
         }
-#pragma unroll
-    for (int k = 0; k < HP; ++k) {
-      const int v = (wave + 4 * k) * 16 + (lane >> 2), p = lane & 3;
-      const int hd = v / 100, rem = v - hd * 100, hh = rem / 10, hw = rem - hh * 10;
-      s.hp[k] = v < HALO_VOX ? (((p ^ (hh & 3)) << 24) | (hd << 16) | (hh << 8) | hw) : -1;
-    }
   }
-#pragma unroll
-  for (int vb = 0; vb < 2; ++vb)
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s.acc[vb][cb][e] = 0.f;
-  s.cur = 0; s.slot = 0; s.res_pending = 0; s.st_pending = 0; s.av_n = -1;
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s.av[cb][j] = 0.f;
-  s.tile = tile0; s.ch = 0;
-  tile_origin(g, tile0, s.n, s.d0, s.h0, s.w0);
-
-  // prologue: first image + weight groups 0 .. P-1, everything landed before the first fragment read
-  issue_halo<NCB>(a, lds, s.hp, wave, 0, 1, s.n, s.d0, s.h0, s.w0, 0);
-  s.a_ch = 0; s.a_j = 0;
-#pragma unroll
-  for (int q = 0; q < KK::P; ++q) {
-    issue_A<NCB>(a, lds, y, wave, lane, s.a_ch, s.a_j, q);
-    if (++s.a_j == KK::NG) { s.a_j = 0; s.a_ch = s.a_ch + 1 == a.nchunks ? 0 : s.a_ch + 1; }
-  }
-  wait_vm<0>();
-  __builtin_amdgcn_s_barrier();
-  s.slot = KK::RD - 1;  // "slot of group -1": group_top<0> steps to slot 0 and refills slot RD-1 with group P
-  s.abase = s.abase_next = KK::RING0 + lane * 16;
+  Seq q;
+  q.tile = tile0; q.ch = 0;
+  tile_origin(a.g, tile0, q.n, q.d0, q.h0, q.w0);
+  load_av<NCB>(s, a, lds, y, wave, lane, q.n);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  init_acc<NCB>(s, lds, wave, lane);
+  s.cur = 0;
+  s.slot = RD - 1;  // "slot of group -1": compute_top<0> steps to slot 0
+  s.abase = s.abase_next = K<NCB>::RING0 + lane * 16;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing of this wave's is in flight across the barriers
+  __builtin_amdgcn_s_barrier();  // prologue: first halo image and weight groups 0, 1 are in LDS
   issue_frags<0, NCB, FLIP>(s.fr[0], s.bcur, s.abase);
   wait_frags<NCB>(s.fr[0]);
   int par = 0;
   while (true) {
-    // next image
-    if (s.ch + 1 < a.nchunks) { s.ntile = s.tile; s.nch = s.ch + 1; s.nn = s.n; s.nd0 = s.d0; s.nh0 = s.h0; s.nw0 = s.w0; }
-    else if (s.tile + tile_step < tile_last) { s.ntile = s.tile + tile_step; s.nch = 0; tile_origin(g, s.ntile, s.nn, s.nd0, s.nh0, s.nw0); }
-    else { s.ntile = -1; s.nch = 0; s.nn = s.nd0 = s.nh0 = s.nw0 = 0; }
-    if (par) taps<0, 1, NCB, FLIP>(s, a, lds, y, wave, lane, fast_res);
-    else taps<0, 0, NCB, FLIP>(s, a, lds, y, wave, lane, fast_res);
+    seq_next(q, a, tile_step, tile_last);
+    if (par) taps<0, 1, NCB, FLIP>(s, lane);
+    else taps<0, 0, NCB, FLIP>(s, lane);
     par ^= 1;
-    if (s.ch == a.nchunks - 1 && !(a.dbg & 1)) epilogue<NCB>(s, a, lds, y, wave, lane, fast_res);
-    if (s.ntile < 0) break;
+    if (q.ch == a.nchunks - 1) {  // tile finished (the next image's first fragments are already on their way)
+      if (!(a.dbg & 1)) stage_acc<NCB>(s, lds, wave, lane);
+      if (q.ntile >= 0 && q.nn != s.av_n) {  // image index changed: once in thousands of tiles
+        load_av<NCB>(s, a, lds, y, wave, lane, q.nn);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      init_acc<NCB>(s, lds, wave, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging written before the barrier that hands it to the store waves
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q.ntile < 0) break;
     s.cur ^= 1;
-    s.tile = s.ntile; s.ch = s.nch; s.n = s.nn; s.d0 = s.nd0; s.h0 = s.nh0; s.w0 = s.nw0;
+    seq_advance(q);
   }
-  wait_vm<0>();  // nothing of this workgroup is in flight when it ends
+  __builtin_amdgcn_s_barrier();  // final: the last tile's staging is complete
+}
+
+// ------------------------------------------------------------------------------------------------ weight-loader waves
+template <int NCB>
+__device__ __forceinline__ void issue_A(const ConvArgs& a, char* lds, int y, int al, int lane, int ch, int j, int slot) {
+  using KK = K<NCB>;
+  const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpk, a.wpk_bytes);
+  // fragments are packed [cout group][chunk][tap][ks][cb] and every chunk of a k3 s1 conv has all 27 taps: no table lookup
+  // (a load inside the loop would be a VECTOR load -- the kernel stores to global memory -- and drain the DMA queue)
+  const int wfrag = (y * a.nchunks + ch) * (27 * 2 * NCB) + j * KK::FRAGS;
+#pragma unroll
+  for (int i = 0; i < KK::FRAGS / 2; ++i) {
+    const int f = al + 2 * i;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + KK::RING0 + slot * KK::GROUP_BYTES + f * 1024), 16, lane * 16,
+                                             (wfrag + f) * 1024, 0, 0);
+  }
+}
+
+template <int NCB>
+__device__ __forceinline__ void wload_role(const ConvArgs& a, char* lds, int y, int al, int lane, int tile0, int tile_step, int tile_last) {
+  using KK = K<NCB>;
+  const bool resident = a.nchunks == 1 && KK::NG <= RD;  // the ring holds every group of the only chunk: load once
+  int a_ch = 0, a_j = 0, slot = 0, issued = 0;
+  auto issue_next = [&]() {
+    if (!(resident && issued >= KK::NG)) issue_A<NCB>(a, lds, y, al, lane, a_ch, a_j, slot);
+    issued = issued < 1000 ? issued + 1 : issued;
+    slot = slot + 1 == RD ? 0 : slot + 1;
+    if (++a_j == KK::NG) { a_j = 0; a_ch = a_ch + 1 == a.nchunks ? 0 : a_ch + 1; }
+  };
+  issue_next();
+  issue_next();  // two groups ahead
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();  // prologue
+  Seq q;
+  q.tile = tile0; q.ch = 0;
+  tile_origin(a.g, tile0, q.n, q.d0, q.h0, q.w0);
+  while (true) {
+    seq_next(q, a, tile_step, tile_last);
+    for (int j = 0; j < KK::NG; ++j) {
+      wait_vm<0>();                  // group j+1 (requested one group ago) has landed
+      __builtin_amdgcn_s_barrier();
+      issue_next();                  // group j+2 into the slot of group j-1, which every compute wave has left
+    }
+    if (q.ntile < 0) break;
+    seq_advance(q);
+  }
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();  // final
+}
+
+// ------------------------------------------------------------------------------------------------ halo-loader / store waves
+__device__ __forceinline__ void issue_halo(const ConvArgs& a, char* lds, const int (&hp)[HPW], int hl, int buf, int valid, int n, int d0, int h0,
+                                           int w0, int src_c0) {
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+#pragma unroll
+  for (int k = 0; k < HPW; ++k) {
+    const int pk = hp[k];
+    const int gd = d0 - 1 + ((pk >> 16) & 255), gh = h0 - 1 + ((pk >> 8) & 255), gw = w0 - 1 + (pk & 255);
+    const int c = src_c0 + ((pk >> 24) & 3) * 8;
+    const bool ok = (valid != 0) & (pk >= 0) & ((unsigned)gd < (unsigned)a.Di) & ((unsigned)gh < (unsigned)a.Hi) & ((unsigned)gw < (unsigned)a.Wi) &
+                    (c + 8 <= a.Cin);  // (bitwise: one select, no branches)
+    const unsigned off = ok ? (unsigned)((((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.x_cs + c) * 2u : 0xfffffff0u;  // out of range -> zeros
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(lds + buf * HALO_BYTES + (hl + 2 * k) * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+// Store epilogue of one tile, this wave's two d-slices.  Piece p (0 .. PIECES-1): slice sl = 2*hl + p / PV, 16 voxels x PV slots
+// per wave-instruction, so that consecutive lanes cover consecutive 16-byte slots of a voxel and then the next voxel along W.
+template <int NCB>
+struct Epi {
+  int n, d0, h0, w0;             // the tile being stored
+  int active;                    // a tile is pending
+  u32x4 res[K<NCB>::PIECES];     // residual pieces (zeros when there is none)
+};
+template <int NCB>
+__device__ __forceinline__ void epi_geometry(const Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane, int p, int& sl, int& v, int& sidx,
+                                             bool& inside, unsigned& vox) {
+  using KK = K<NCB>;
+  sl = 2 * hl + p / KK::PV;
+  const int q = (p % KK::PV) * 64 + lane;
+  v = q / KK::PV;
+  sidx = q % KK::PV;
+  const int od = e.d0 + sl, oh = e.h0 + (v >> 3), ow = e.w0 + (v & 7);
+  const int co = y * NCB * 32 + sidx * 8;
+  inside = (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co + 8 <= a.Cout);
+  vox = (unsigned)(((e.n * a.Do + od) * a.Ho + oh) * a.Wo + ow);
+}
+template <int NCB>
+__device__ __forceinline__ void epi_issue_res(Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane) {
+  using KK = K<NCB>;
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res_bytes);
+#pragma unroll
+  for (int p = 0; p < KK::PIECES; ++p) {
+    int sl, v, sidx; bool inside; unsigned vox;
+    epi_geometry<NCB>(e, a, y, hl, lane, p, sl, v, sidx, inside, vox);
+    const unsigned off = inside ? (vox * (unsigned)a.res_cs + (unsigned)(y * NCB * 32 + sidx * 8)) * 2u : 0xfffffff0u;
+    e.res[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0));
+  }
+}
+template <int P0, int CNT, int NCB>
+__device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, bool has_res, bool vec_ok) {
+  using KK = K<NCB>;
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y, a.y_bytes);
+#pragma unroll
+  for (int p = P0; p < P0 + CNT; ++p) {
+    if (p >= KK::PIECES) break;
+    int sl, v, sidx; bool inside; unsigned vox;
+    epi_geometry<NCB>(e, a, y, hl, lane, p, sl, v, sidx, inside, vox);
+    const char* stg = lds + KK::STG0 + sl * KK::STG_WAVE;
+    u32x4 raw = *(const u32x4*)(stg + v * KK::VOXP + ((sidx ^ (v & (KK::PV - 1))) * 16));
+    const int co = y * NCB * 32 + sidx * 8;
+    if (has_res) {
+      F8 f = unpack8(raw), rr = unpack8(e.res[p]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] += rr.v[j];
+      raw = pack8(f);
+    }
+    if (vec_ok) {  // always issued (masked lanes get an out-of-range offset)
+      const unsigned off = inside ? (vox * (unsigned)a.y_cs + (unsigned)co) * 2u : 0xfffffff0u;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, raw), ry, (int)off, 0, 0);
+    } else {  // ragged channel counts (Cout = 1, ...): element-wise
+      const int od = e.d0 + sl, oh = e.h0 + (v >> 3), ow = e.w0 + (v & 7);
+      if ((od < a.Do) & (oh < a.Ho) & (ow < a.Wo)) {
+        F8 f = unpack8(raw);
+        bf16* yp = a.y + (int64_t)vox * a.y_cs + co;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (co + j < a.Cout) yp[j] = f2bf(f.v[j]);
+      }
+    }
+  }
+}
+// pieces of tap group J (1 .. NG-1) of the image during which a tile is stored
+template <int J, int NCB>
+__device__ __forceinline__ void epi_group(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, int j, bool has_res, bool vec_ok) {
+  using KK = K<NCB>;
+  if constexpr (J < KK::NG) {
+    if (j == J) epi_process<(J - 1) * KK::PPT, KK::PPT, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
+    else epi_group<J + 1, NCB>(e, a, lds, y, hl, lane, j, has_res, vec_ok);
+  }
+}
+
+template <int NCB>
+__device__ __forceinline__ void hload_role(const ConvArgs& a, char* lds, int y, int hl, int lane, int tile0, int tile_step, int tile_last) {
+  using KK = K<NCB>;
+  int hp[HPW];  // this lane's halo DMA pieces: (logical slot << 24) | (hd << 16) | (hh << 8) | hw, or -1
+#pragma unroll
+  for (int k = 0; k < HPW; ++k) {
+    const int v = (hl + 2 * k) * 16 + (lane >> 2), p = lane & 3;
+    const int hd = v / 100, rem = v - hd * 100, hh = rem / 10, hw = rem - hh * 10;
+    hp[k] = v < HALO_VOX ? (((p ^ (hh & 3)) << 24) | (hd << 16) | (hh << 8) | hw) : -1;
+  }
+  const bool has_res = a.res != nullptr;
+  const bool vec_ok = (a.y_cs & 7) == 0 && (a.Cout & 7) == 0 && a.y_bytes != 0;
+  Seq q;
+  q.tile = tile0; q.ch = 0;
+  tile_origin(a.g, tile0, q.n, q.d0, q.h0, q.w0);
+  issue_halo(a, lds, hp, hl, 0, 1, q.n, q.d0, q.h0, q.w0, 0);
+  wait_vm<0>();
+  __builtin_amdgcn_s_barrier();  // prologue
+  Epi<NCB> e;
+  e.active = 0; e.n = e.d0 = e.h0 = e.w0 = 0;
+#pragma unroll
+  for (int p = 0; p < KK::PIECES; ++p) e.res[p] = u32x4{0u, 0u, 0u, 0u};
+  int cur = 0;
+  while (true) {
+    seq_next(q, a, tile_step, tile_last);
+    // group 0: the other halo buffer is free once every compute wave has passed this barrier
+    __builtin_amdgcn_s_barrier();
+    if (e.active && has_res) epi_issue_res<NCB>(e, a, y, hl, lane);  // issued BEFORE the halo requests: usable without waiting for them
+    issue_halo(a, lds, hp, hl, cur ^ 1, q.ntile >= 0, q.nn, q.nd0, q.nh0, q.nw0, q.nch * 32);
+    // groups 1 .. NG-2: a few store pieces after each barrier; group NG-1: the last pieces BEFORE its barrier (a single-chunk
+    // tile's compute waves overwrite the staging tile right after it), then everything but those last stores must have landed
+    for (int j = 1; j < KK::NG - 1; ++j) {
+      __builtin_amdgcn_s_barrier();
+      if (e.active) epi_group<1, NCB>(e, a, lds, y, hl, lane, j, has_res, vec_ok);
+    }
+    if (e.active) {
+      epi_process<(KK::NG - 2) * KK::PPT, KK::PPT, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before the compute waves may overwrite the tile
+      if (vec_ok) wait_vm<KK::PPT>(); else wait_vm<0>();  // the next halo image has landed; only the stores just issued may fly
+      e.active = 0;
+    } else {
+      wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();  // group NG-1
+    if (q.ch == a.nchunks - 1 && !(a.dbg & 1)) { e.active = 1; e.n = q.n; e.d0 = q.d0; e.h0 = q.h0; e.w0 = q.w0; }
+    if (q.ntile < 0) break;
+    cur ^= 1;
+    seq_advance(q);
+  }
+  __builtin_amdgcn_s_barrier();  // final: the last tile's staging is complete
+  if (e.active) {
+    if (has_res) epi_issue_res<NCB>(e, a, y, hl, lane);
+    epi_process<0, KK::PIECES, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
+  }
+  wait_vm<0>();
+}
+
+template <int NCB, int FLIP>
+__global__ void __launch_bounds__(512, 2) k_conv27(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int y = blockIdx.y;
+  int tile_last, tile_step;
+  const int tile0 = first_tile(a.ntiles, tile_last, tile_step);
+  if (tile0 >= tile_last) return;  // whole workgroup, before any barrier
+  if (wave < 4) compute_role<NCB, FLIP>(a, lds, y, wave, lane, tile0, tile_step, tile_last);
+  else if (wave < 6) wload_role<NCB>(a, lds, y, wave - 4, lane, tile0, tile_step, tile_last);
+  else hload_role<NCB>(a, lds, y, wave - 6, lane, tile0, tile_step, tile_last);
 }
 
 template <int NCB, int FLIP>
@@ -462,7 +551,7 @@ int launch27(ConvArgs a, int ntiles, int ny, hipStream_t st) {
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(256), (size_t)KK::LDS_TOTAL, st, a);
+  hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), (size_t)KK::LDS_TOTAL, st, a);
   MI_CHECK_LAUNCH();
   return 0;
 }
@@ -471,6 +560,7 @@ int launch27(ConvArgs a, int ntiles, int ny, hipStream_t st) {
 
 int mi_launch_conv27(const ConvArgs& a, int NCB, int flip, int ntiles, int ny, hipStream_t st) {
   if (a.g.TD != 4 || a.g.TH != 8 || a.g.TW != 8 || (a.x_cs & 7) || (a.Cin & 7)) return MI_ERR_BAD_ARG;
+  if (a.res && (a.res_bytes == 0 || (a.res_cs & 7))) return MI_ERR_UNSUPPORTED;  // (>= 4 GiB is not reachable with the x_bytes limit)
   if (NCB == 1) return flip ? launch27<1, 1>(a, ntiles, ny, st) : launch27<1, 0>(a, ntiles, ny, st);
   if (NCB == 2) return flip ? launch27<2, 1>(a, ntiles, ny, st) : launch27<2, 0>(a, ntiles, ny, st);
   return MI_ERR_BAD_ARG;
