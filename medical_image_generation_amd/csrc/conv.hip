@@ -421,6 +421,7 @@ __global__ void __launch_bounds__(256, WPS) k_conv_igemm(ConvArgs a) {
 struct WgradArgs {
   ConvArgs c;         // x side: loader geometry / tables (NCB = 1 tables); y/res/addvec unused
   const bf16* dy; int dy_cs;
+  unsigned dy_bytes;  // size of dy for its buffer descriptor (LDS-DMA kernel)
   float* part;        // [nsplit][npairs][MAXTAPS? -> ntaps_of_pair][32][32] laid out by pair_off
   const int* pair_off;  // [npairs] float offset of the pair's slab inside one split's partial
   int64_t split_stride; // floats per split
@@ -767,6 +768,244 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
       const int e = f >> 6, ln = f & 63;
       out[((e & 3) + 8 * (e >> 2) + 4 * (ln >> 5)) * 32 + (ln & 31)] = sum;
     }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    int ti = wave + 8 * t;
+    if (ti >= ntaps) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int co = (e & 3) + 8 * (e >> 2) + 4 * h;
+      out[((int64_t)ti * 32 + co) * 32 + r] = acc[t][e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient, LDS-DMA version
+// Same arithmetic as k_conv_wgrad, different plumbing (what conv27.hip showed to matter): the 8 compute waves only read LDS
+// and issue MFMAs; 4 loader waves (2 for the x halo image, 2 for the dY tile) fill DOUBLE-BUFFERED dense images by LDS-DMA
+// (buffer_load ... lds; the hardware range check supplies zero padding and the ragged volume edge) one tile ahead, and there is
+// ONE s_barrier per tile: it publishes tile i+1's images (loaders wait vmcnt(0) first) and frees tile i's buffers.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+template <int MAXP>
+struct DmaPieces {
+  int pk[MAXP];  // per piece of this wave: packed coordinates of the lane's voxel ((a << 20) | (b << 10) | c) or -1
+};
+
+// x halo image: piece i (1 KiB) -> halo voxels 16 i .. 16 i + 15, lane -> voxel 16 i + (lane >> 2), 16-byte part lane & 3
+template <int MAXP>
+__device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane) {
+  const int hvox = g.HD * g.HH * g.HW;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int i = first + stride * k;
+    const int v = i * 16 + (lane >> 2);
+    const int hd = v / (g.HH * g.HW), rem = v - hd * (g.HH * g.HW), hh = rem / g.HW, hw = rem - hh * g.HW;
+    d.pk[k] = (i < npieces && v < hvox) ? ((hd << 20) | (hh << 10) | hw) : -1;
+  }
+}
+template <int MAXP>
+__device__ __forceinline__ void dma_issue_x(const DmaPieces<MAXP>& d, const ConvArgs& a, char* dst, int first, int stride, int npieces, int lane,
+                                            int n, int d0, int h0, int w0, int src_c0) {
+  const Geom& g = a.g;
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  const int c = src_c0 + (lane & 3) * 8;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int i = first + stride * k;
+    if (i >= npieces) break;  // wave-uniform
+    const int pk = d.pk[k];
+    const int gd = d0 - g.hd + (pk >> 20), gh = h0 - g.hh + ((pk >> 10) & 1023), gw = w0 - g.hw + (pk & 1023);
+    const bool ok = (pk >= 0) & ((unsigned)gd < (unsigned)a.Di) & ((unsigned)gh < (unsigned)a.Hi) & ((unsigned)gw < (unsigned)a.Wi) & (c + 8 <= a.Cin);
+    const unsigned off = ok ? (unsigned)((((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.x_cs + c) * 2u : 0xfffffff0u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(dst + i * 1024), 16, off, 0, 0, 0);
+  }
+}
+// dY tile image: [TD][TH][TW] voxels x 64 B, channels y*32 ..
+template <int MAXP>
+__device__ __forceinline__ void dma_init_y(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane) {
+  const int nvox = g.TD * g.TH * g.TW;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int i = first + stride * k;
+    const int v = i * 16 + (lane >> 2);
+    const int vd = v / (g.TH * g.TW), rem = v - vd * (g.TH * g.TW), vh = rem / g.TW, vw = rem - vh * g.TW;
+    d.pk[k] = (i < npieces && v < nvox) ? ((vd << 20) | (vh << 10) | vw) : -1;
+  }
+}
+template <int MAXP>
+__device__ __forceinline__ void dma_issue_y(const DmaPieces<MAXP>& d, const WgradArgs& w, char* dst, int first, int stride, int npieces, int lane,
+                                            int y, int n, int d0, int h0, int w0) {
+  const ConvArgs& a = w.c;
+  const __amdgpu_buffer_rsrc_t ry = make_rsrc(w.dy, w.dy_bytes);
+  const int co = y * 32 + (lane & 3) * 8;
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int i = first + stride * k;
+    if (i >= npieces) break;
+    const int pk = d.pk[k];
+    const int od = d0 + (pk >> 20), oh = h0 + ((pk >> 10) & 1023), ow = w0 + (pk & 1023);
+    const bool ok = (pk >= 0) & (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co + 8 <= a.Cout);
+    const unsigned off = ok ? (unsigned)((((n * a.Do + od) * a.Ho + oh) * a.Wo + ow) * w.dy_cs + co) * 2u : 0xfffffff0u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void_t*)(dst + i * 1024), 16, off, 0, 0, 0);
+  }
+}
+
+template <bool GEO3D>
+__global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
+  constexpr int MAXT = 4, MAXPX = 20, MAXPY = 8;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const ConvArgs& a = w.c;
+  const Geom& g = a.g;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nvox = g.TD * g.TH * g.TW;
+  const int px = (g.lds_bytes + 1023) >> 10, py = (nvox * 64 + 1023) >> 10;  // 1-KiB pieces per image
+  const int XB = px << 10, YB = py << 10;
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned lds_base = (unsigned)(size_t)(lds_char*)lds;
+  int pair, split;
+  if (w.nsplit >= 8) {  // XCD-aware placement: see k_conv_wgrad
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    pair = slot % w.npairs;
+    split = (slot / w.npairs) * 8 + xcd;
+  } else {
+    pair = blockIdx.x / w.nsplit;
+    split = blockIdx.x % w.nsplit;
+  }
+  if (split >= w.nsplit || pair >= w.npairs || split >= w.ntiles) return;  // whole workgroup, before any barrier
+  const int y = pair / a.nchunks;
+  const int* hdr = a.hdr + (int64_t)pair * 4;
+  const int tap_begin = hdr[0], ntaps = hdr[1], src_c0 = hdr[2];
+  const bool ksplit = !GEO3D && ntaps == 1;
+
+  if (wave >= 8) {  // ---------------------------------------------------------------- loader waves
+    const bool is_x = wave < 10;
+    const int first = is_x ? wave - 8 : wave - 10;
+    DmaPieces<MAXPX> dx;
+    DmaPieces<MAXPY> dyp;
+    if (is_x) dma_init_x<MAXPX>(dx, g, first, 2, px, lane);
+    else dma_init_y<MAXPY>(dyp, g, first, 2, py, lane);
+    int tile = split, n, d0, h0, w0, buf = 0;
+    tile_origin(g, tile, n, d0, h0, w0);
+    if (is_x) dma_issue_x<MAXPX>(dx, a, lds, first, 2, px, lane, n, d0, h0, w0, src_c0);
+    else dma_issue_y<MAXPY>(dyp, w, lds + 2 * XB, first, 2, py, lane, y, n, d0, h0, w0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // prologue
+    while (true) {
+      const int next = tile + w.nsplit;
+      if (next < w.ntiles) {  // the other buffer was released by the barrier that ended the previous iteration
+        tile_origin(g, next, n, d0, h0, w0);
+        if (is_x) dma_issue_x<MAXPX>(dx, a, lds + (buf ^ 1) * XB, first, 2, px, lane, n, d0, h0, w0, src_c0);
+        else dma_issue_y<MAXPY>(dyp, w, lds + 2 * XB + (buf ^ 1) * YB, first, 2, py, lane, y, n, d0, h0, w0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (next >= w.ntiles) break;
+      tile = next;
+      buf ^= 1;
+    }
+    if (ksplit) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }  // the compute waves' fold
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------ compute waves (as k_conv_wgrad)
+  const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int kh = gq >> 1;
+  const int chan_b = ((gq & 1) * 16 + pp * 4) * 2;
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  int toff[MAXT];
+  int nt = 0;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    int ti = wave + 8 * t;
+    toff[t] = a.taps[tap_begin + (ti < ntaps ? ti : 0)];
+    nt += ti < ntaps ? 1 : 0;
+  }
+  const int dyrow = g.TW * g.vox, dyslice = g.TH * dyrow;
+  int tile = split, n, d0, h0, w0, buf = 0;
+  tile_origin(g, tile, n, d0, h0, w0);
+  const bool do_colsum = w.colsum != nullptr && (pair % a.nchunks) == 0;
+  const bool cs_wave = do_colsum && (ksplit || wave == 7);
+  f32x16& cs = acc[3];
+  auto cs_flush = [&](int img) {
+    if ((lane & 31) == 0) {
+      const int hh = lane >> 5;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = y * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (co < a.Cout) atomicAdd(w.colsum + (int64_t)img * w.colsum_stride + co, cs[e]);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[e] = 0.f;
+  };
+  int cs_n = n;
+  __builtin_amdgcn_s_barrier();  // prologue: tile 0 is in buffer 0
+  while (true) {
+    if (cs_wave && n != cs_n) {
+      cs_flush(cs_n);
+      cs_n = n;
+    }
+    const unsigned lds0 = lds_base + buf * XB, ldy0 = lds_base + 2 * XB + buf * YB;
+    {
+      f32x16(&a3)[3] = reinterpret_cast<f32x16(&)[3]>(acc);
+      const int(&t3)[3] = reinterpret_cast<const int(&)[3]>(toff);
+      if constexpr (GEO3D) {
+        if (nt == 4) wg3_tile<4, false>(acc, toff, cs, lds0, ldy0, kh, q, chan_b);
+        else if (cs_wave) wg3_tile<3, true>(a3, t3, cs, lds0, ldy0, kh, q, chan_b);
+        else wg3_tile<3, false>(a3, t3, cs, lds0, ldy0, kh, q, chan_b);
+      } else {
+        f32x16(&a2)[2] = reinterpret_cast<f32x16(&)[2]>(acc);
+        const int(&t2)[2] = reinterpret_cast<const int(&)[2]>(toff);
+        f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc);
+        const int(&t1)[1] = reinterpret_cast<const int(&)[1]>(toff);
+        if (ksplit) {
+          if (cs_wave) wg_tile_ksplit<true>(a1, t1, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, wave);
+          else wg_tile_ksplit<false>(a1, t1, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, wave);
+        } else if (cs_wave) {
+          if (nt == 3) wg_tile<3, true>(a3, t3, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, 0);
+          else if (nt == 2) wg_tile<2, true>(a2, t2, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, 0);
+          else if (nt == 1) wg_tile<1, true>(a1, t1, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, 0);
+          else wg_tile<0, true>(a1, t1, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, 0);
+        } else {
+          if (nt == 4) wg_tile<4, false>(acc, toff, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, 0);
+          else if (nt == 3) wg_tile<3, false>(a3, t3, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, 0);
+          else if (nt == 2) wg_tile<2, false>(a2, t2, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, 0);
+          else if (nt == 1) wg_tile<1, false>(a1, t1, cs, g, lds0, ldy0, kh, q, chan_b, dyrow, dyslice, 0);
+        }
+      }
+    }
+    __builtin_amdgcn_s_barrier();  // this tile's buffers are free; the next tile's images have landed
+    const int next = tile + w.nsplit;
+    if (next >= w.ntiles) break;
+    tile = next;
+    buf ^= 1;
+    tile_origin(g, tile, n, d0, h0, w0);
+  }
+  if (cs_wave) cs_flush(cs_n);
+
+  float* out = w.part + (int64_t)split * w.split_stride + w.pair_off[pair];
+  const int r = lane & 31, h = lane >> 5;
+  if (ksplit) {  // fold the 8 waves' partial accumulators of the single tap through LDS (the images are dead by now)
+    float* red = (float*)lds;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[(wave * 16 + e) * 64 + lane] = acc[0][e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int f = threadIdx.x; f < 1024; f += 512) {
+      float sum = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < 8; ++wv) sum += red[wv * 1024 + f];
+      const int e = f >> 6, ln = f & 63;
+      out[((e & 3) + 8 * (e >> 2) + 4 * (ln >> 5)) * 32 + (ln & 31)] = sum;
+    }
+    __builtin_amdgcn_s_barrier();
     return;
   }
 #pragma unroll
@@ -1294,6 +1533,33 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
     }                                                                                                              \
     hipLaunchKernelGGL(kern, grid, blk, lds, st, w);                                                               \
   } while (0)
+  // LDS-DMA kernel (k_conv_wgrad2): whole 8-channel pieces only, no fused prologue
+  static const int use_w2 = env_int("MI_WGRAD2", 1);
+  {
+    const int px = (a.g.lds_bytes + 1023) / 1024, py = (nvox * 64 + 1023) / 1024;
+    const int64_t dyb = (int64_t)P->N * P->Do * P->Ho * P->Wo * dy_cs * 2;
+    if (use_w2 && P->KT > 1 && !scale_shift && a.g.vox == 64 &&  // (1x1 convs: the k-split path is faster on the register-staged kernel)
+        (a.x_cs & 7) == 0 && (a.Cin & 7) == 0 && (dy_cs & 7) == 0 && (P->Cout & 7) == 0 && px <= 40 &&
+        py <= 16 && dyb < (1ll << 32)) {
+      w.dy_bytes = (unsigned)dyb;
+      const size_t lds2 = (size_t)(2 * px + 2 * py) * 1024;
+      const bool geo3 = P->full27 && a.g.row == WG3_XROW && a.g.slice == WG3_XSLICE && a.g.TD == 4 && a.g.TH == 8 && a.g.TW == 8;
+      static bool attr3 = false, attrg = false;
+      bool& done = geo3 ? attr3 : attrg;
+      if (!done) {
+        hipError_t e = geo3 ? hipFuncSetAttribute((const void*)k_conv_wgrad2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                            : hipFuncSetAttribute((const void*)k_conv_wgrad2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+      }
+      if (geo3) hipLaunchKernelGGL(k_conv_wgrad2<true>, grid, dim3(768), lds2, st, w);
+      else hipLaunchKernelGGL(k_conv_wgrad2<false>, grid, dim3(768), lds2, st, w);
+      hipLaunchKernelGGL(k_wgrad_reduce, dim3(P->wg_nitems * 16), dim3(256), 0, st, P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems,
+                         P->wg_nitems, dw, P->Cout, P->Cin, P->KT);
+      MI_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const int np8 = (hv * 4 + 511) / 512;
   const bool geo3d = P->full27 && a.g.vox == 64 && a.g.row == WG3_XROW && a.g.slice == WG3_XSLICE && a.g.TD == 4 && a.g.TH == 8 &&
                      a.g.TW == 8 && np8 == 5;
