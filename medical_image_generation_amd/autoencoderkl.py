@@ -164,7 +164,7 @@ class AutoencoderKL(HipModule):
                 n2 = E.gn(c, h, name + ".norm2", self.groups, self.eps)
                 xs = x
                 if name + ".nin_shortcut.conv.weight" in c.arena.offsets:
-                    xs = E.conv(c, x, name + ".nin_shortcut.conv", (1, 1, 1), self._s1, (0, 0, 0))
+                    xs = E.conv(c, x, name + ".nin_shortcut.conv", (1, 1, 1), self._s1, (0, 0, 0), bias_grad_like=name + ".conv2.conv")
                 x = E.conv(c, h, name + ".conv2.conv", self._k3, self._s1, self._p1, norm=n2, silu=True, res=xs)
             elif kind == "attn":
                 x = E.attention(c, x, name, self.groups, self.eps, 1)  # num_head_channels=None -> one head (AEKL:235)

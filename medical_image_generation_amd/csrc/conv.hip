@@ -422,6 +422,7 @@ struct WgradArgs {
   ConvArgs c;         // x side: loader geometry / tables (NCB = 1 tables); y/res/addvec unused
   const bf16* dy; int dy_cs;
   unsigned dy_bytes;  // size of dy for its buffer descriptor (LDS-DMA kernel)
+  int nbuf;           // LDS-DMA kernel: image ring depth (2; 4 for 1x1 pairs)
   float* part;        // [nsplit][npairs][MAXTAPS? -> ntaps_of_pair][32][32] laid out by pair_off
   const int* pair_off;  // [npairs] float offset of the pair's slab inside one split's partial
   int64_t split_stride; // floats per split
@@ -808,7 +809,7 @@ __device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, in
 }
 template <int MAXP>
 __device__ __forceinline__ void dma_issue_x(const DmaPieces<MAXP>& d, const ConvArgs& a, char* dst, int first, int stride, int npieces, int lane,
-                                            int n, int d0, int h0, int w0, int src_c0) {
+                                            int n, int d0, int h0, int w0, int src_c0, bool valid = true) {
   const Geom& g = a.g;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
   const int c = src_c0 + (lane & 3) * 8;
@@ -818,7 +819,7 @@ __device__ __forceinline__ void dma_issue_x(const DmaPieces<MAXP>& d, const Conv
     if (i >= npieces) break;  // wave-uniform
     const int pk = d.pk[k];
     const int gd = d0 - g.hd + (pk >> 20), gh = h0 - g.hh + ((pk >> 10) & 1023), gw = w0 - g.hw + (pk & 1023);
-    const bool ok = (pk >= 0) & ((unsigned)gd < (unsigned)a.Di) & ((unsigned)gh < (unsigned)a.Hi) & ((unsigned)gw < (unsigned)a.Wi) & (c + 8 <= a.Cin);
+    const bool ok = valid & (pk >= 0) & ((unsigned)gd < (unsigned)a.Di) & ((unsigned)gh < (unsigned)a.Hi) & ((unsigned)gw < (unsigned)a.Wi) & (c + 8 <= a.Cin);
     const unsigned off = ok ? (unsigned)((((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.x_cs + c) * 2u : 0xfffffff0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(dst + i * 1024), 16, off, 0, 0, 0);
   }
@@ -837,7 +838,7 @@ __device__ __forceinline__ void dma_init_y(DmaPieces<MAXP>& d, const Geom& g, in
 }
 template <int MAXP>
 __device__ __forceinline__ void dma_issue_y(const DmaPieces<MAXP>& d, const WgradArgs& w, char* dst, int first, int stride, int npieces, int lane,
-                                            int y, int n, int d0, int h0, int w0) {
+                                            int y, int n, int d0, int h0, int w0, bool valid = true) {
   const ConvArgs& a = w.c;
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(w.dy, w.dy_bytes);
   const int co = y * 32 + (lane & 3) * 8;
@@ -847,7 +848,7 @@ __device__ __forceinline__ void dma_issue_y(const DmaPieces<MAXP>& d, const Wgra
     if (i >= npieces) break;
     const int pk = d.pk[k];
     const int od = d0 + (pk >> 20), oh = h0 + ((pk >> 10) & 1023), ow = w0 + (pk & 1023);
-    const bool ok = (pk >= 0) & (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co + 8 <= a.Cout);
+    const bool ok = valid & (pk >= 0) & (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co + 8 <= a.Cout);
     const unsigned off = ok ? (unsigned)((((n * a.Do + od) * a.Ho + oh) * a.Wo + ow) * w.dy_cs + co) * 2u : 0xfffffff0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void_t*)(dst + i * 1024), 16, off, 0, 0, 0);
   }
@@ -887,25 +888,37 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     DmaPieces<MAXPY> dyp;
     if (is_x) dma_init_x<MAXPX>(dx, g, first, 2, px, lane);
     else dma_init_y<MAXPY>(dyp, g, first, 2, py, lane);
-    int tile = split, n, d0, h0, w0, buf = 0;
-    tile_origin(g, tile, n, d0, h0, w0);
-    if (is_x) dma_issue_x<MAXPX>(dx, a, lds, first, 2, px, lane, n, d0, h0, w0, src_c0);
-    else dma_issue_y<MAXPY>(dyp, w, lds + 2 * XB, first, 2, py, lane, y, n, d0, h0, w0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // prologue
+    // ring of NB image pairs (w.nbuf: 2, or 4 for the 1x1 k-split pairs whose tiles are all loads and hardly any MFMA): tile i
+    // lives in slot i % NB and is requested NB-1 tiles ahead.  Requests beyond the last tile are still issued (all lanes out of
+    // range: zeros into a free slot) so that the counted vmcnt below stays exact.
+    const int NB = w.nbuf;
+    auto request = [&](int t, int slot) {
+      int n, d0, h0, w0;
+      const bool valid = t < w.ntiles;
+      tile_origin(g, valid ? t : split, n, d0, h0, w0);
+      if (is_x) dma_issue_x<MAXPX>(dx, a, lds + slot * XB, first, 2, px, lane, n, d0, h0, w0, src_c0, valid);
+      else dma_issue_y<MAXPY>(dyp, w, lds + NB * XB + slot * YB, first, 2, py, lane, y, n, d0, h0, w0, valid);
+    };
+    auto wait_next = [&]() {  // everything but the NB-2 youngest tiles of this wave has landed (8 pieces per tile and wave when NB = 4)
+      if (NB == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    int tile = split, slot = 0;
+    for (int k = 0; k < NB - 1; ++k) request(tile + k * w.nsplit, k);
+    if (NB == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // prologue: tile 0 has landed
     while (true) {
       const int next = tile + w.nsplit;
-      if (next < w.ntiles) {  // the other buffer was released by the barrier that ended the previous iteration
-        tile_origin(g, next, n, d0, h0, w0);
-        if (is_x) dma_issue_x<MAXPX>(dx, a, lds + (buf ^ 1) * XB, first, 2, px, lane, n, d0, h0, w0, src_c0);
-        else dma_issue_y<MAXPY>(dyp, w, lds + 2 * XB + (buf ^ 1) * YB, first, 2, py, lane, y, n, d0, h0, w0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int free_slot = slot == 0 ? NB - 1 : slot - 1;  // released by the barrier that ended the previous iteration
+      request(tile + (NB - 1) * w.nsplit, free_slot);
+      wait_next();
       __builtin_amdgcn_s_barrier();
       if (next >= w.ntiles) break;
       tile = next;
-      buf ^= 1;
+      slot = slot + 1 == NB ? 0 : slot + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (ksplit) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }  // the compute waves' fold
     return;
   }
@@ -929,6 +942,7 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
   }
   const int dyrow = g.TW * g.vox, dyslice = g.TH * dyrow;
   int tile = split, n, d0, h0, w0, buf = 0;
+  const int NB = w.nbuf;
   tile_origin(g, tile, n, d0, h0, w0);
   const bool do_colsum = w.colsum != nullptr && (pair % a.nchunks) == 0;
   const bool cs_wave = do_colsum && (ksplit || wave == 7);
@@ -946,13 +960,13 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     for (int e = 0; e < 16; ++e) cs[e] = 0.f;
   };
   int cs_n = n;
-  __builtin_amdgcn_s_barrier();  // prologue: tile 0 is in buffer 0
+  __builtin_amdgcn_s_barrier();  // prologue: tile 0 is in slot 0
   while (true) {
     if (cs_wave && n != cs_n) {
       cs_flush(cs_n);
       cs_n = n;
     }
-    const unsigned lds0 = lds_base + buf * XB, ldy0 = lds_base + 2 * XB + buf * YB;
+    const unsigned lds0 = lds_base + buf * XB, ldy0 = lds_base + NB * XB + buf * YB;
     {
       f32x16(&a3)[3] = reinterpret_cast<f32x16(&)[3]>(acc);
       const int(&t3)[3] = reinterpret_cast<const int(&)[3]>(toff);
@@ -985,7 +999,7 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     const int next = tile + w.nsplit;
     if (next >= w.ntiles) break;
     tile = next;
-    buf ^= 1;
+    buf = buf + 1 == NB ? 0 : buf + 1;
     tile_origin(g, tile, n, d0, h0, w0);
   }
   if (cs_wave) cs_flush(cs_n);
@@ -1134,6 +1148,7 @@ struct mi_conv_plan {
   bool strided = false;
   bool full27 = false;  // k3 s1 p1 on all three axes: compile-time tap nest
   bool v27_fwd = false, v27_dg = false;  // forward / data gradient run on conv27.hip (LDS-DMA kernel); weights packed with perm16
+  bool v11_fwd = false, v11_dg = false;  // 1x1x1: forward / data gradient run on conv1x1.hip (streaming GEMM); weights packed with perm16
 };
 
 namespace {
@@ -1327,10 +1342,17 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   const bool geo27 = P->full27 && P->g_fwd.TD == 4 && P->g_fwd.TH == 8 && P->g_fwd.TW == 8;
   P->v27_fwd = use27 && geo27 && (Cin % 8) == 0;
   P->v27_dg = use27 && geo27 && (Cout % 8) == 0;
-  build_tables(P->fwd, P->g_fwd, P->ncb_fwd, cf, P->f, P->k, true, Cin, Cout, false, P->v27_fwd);
+  {
+    static const int use11 = env_int("MI_CONV1X1", 1);
+    const bool k1 = P->KT == 1 && !P->strided;
+    auto chunks_ok = [](int c) { int n = (c + 31) / 32; return n == 1 || n == 2 || n == 3 || n == 4 || n == 6; };
+    P->v11_fwd = use11 && k1 && (Cin % 8) == 0 && chunks_ok(Cin) && ((Cout + 31) / 32) * ((Cin + 31) / 32) * 2 <= 96;
+    P->v11_dg = use11 && k1 && (Cout % 8) == 0 && chunks_ok(Cout) && ((Cout + 31) / 32) * ((Cin + 31) / 32) * 2 <= 96;
+  }
+  build_tables(P->fwd, P->g_fwd, P->ncb_fwd, cf, P->f, P->k, true, Cin, Cout, false, P->v27_fwd || P->v11_fwd);
   // dgrad: loader reads dy (Do,Ho,Wo,Cout); outputs the depth image of dx on the (Dp,Hp,Wp) grid with Q*Cin channels
   P->g_dg = make_geom(2, P->Dp, P->Hp, P->Wp, halo_d, N);
-  build_tables(P->dg, P->g_dg, P->ncb_dg, cdg, P->f, P->k, false, Cout, Cin, true, P->v27_dg);
+  build_tables(P->dg, P->g_dg, P->ncb_dg, cdg, P->f, P->k, false, Cout, Cin, true, P->v27_dg || P->v11_dg);
   // wgrad: forward geometry, 32-cout groups
   P->g_wg = make_geom(2, P->Do, P->Ho, P->Wo, halo_f, N, 64);
   build_tables(P->wg, P->g_wg, 1, cf, P->f, P->k, true, Cin, Cout, false);
@@ -1425,7 +1447,12 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
     if (xb >= (1ll << 32)) return MI_ERR_UNSUPPORTED;
     a.x_bytes = (unsigned)xb;
   }
-  a.perm16 = P->v27_fwd;
+  a.perm16 = P->v27_fwd || P->v11_fwd;
+  if (P->v11_fwd && !scale_shift && !res && (x_cs & 7) == 0) {
+    const int64_t yb = (int64_t)P->N * P->Do * P->Ho * P->Wo * y_cs * 2;
+    a.y_bytes = yb < (1ll << 32) ? (unsigned)yb : 0u;
+    return mi_launch_conv1x1(a, P->ncb_fwd, P->fwd.ny, st);
+  }
   if (P->v27_fwd && !scale_shift) {  // (the fused GroupNorm prologue lives in the register-staged kernel)
     if (x_cs & 7) return MI_ERR_UNSUPPORTED;
     const int64_t rb = res ? (int64_t)P->N * P->Do * P->Ho * P->Wo * res_cs * 2 : 0;
@@ -1460,7 +1487,12 @@ int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_c
     if (xb >= (1ll << 32)) return MI_ERR_UNSUPPORTED;
     a.x_bytes = (unsigned)xb;
   }
-  a.perm16 = P->v27_dg;
+  a.perm16 = P->v27_dg || P->v11_dg;
+  if (P->v11_dg && (dy_cs & 7) == 0) {
+    const int64_t yb = (int64_t)P->N * a.Do * a.Ho * a.Wo * a.y_cs * 2;
+    a.y_bytes = yb < (1ll << 32) ? (unsigned)yb : 0u;
+    return mi_launch_conv1x1(a, P->ncb_dg, P->dg.ny, st);
+  }
   if (P->v27_dg) {
     if (dy_cs & 7) return MI_ERR_UNSUPPORTED;
     const int64_t yb = (int64_t)P->N * a.Do * a.Ho * a.Wo * a.y_cs * 2;
@@ -1477,6 +1509,11 @@ int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_c
 int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const void* dy, int dy_cs, float* dw,
                   float* dy_colsum, int dy_colsum_stride, hipStream_t st) {
   if (!P || !x || !dy || !dw || x_cs < P->Cin || dy_cs < P->Cout) return MI_ERR_BAD_ARG;
+  static const int use_w11 = env_int("MI_WGRAD1X1", 1);
+  if (use_w11 && P->KT == 1 && !P->strided && !scale_shift && !(dy_colsum && dy_colsum_stride != 0 && dy_colsum_stride < P->Cout)) {
+    int e = mi_launch_wgrad1x1(x, x_cs, P->Cin, dy, dy_cs, P->Cout, P->N, (int64_t)P->Di * P->Hi * P->Wi, dw, dy_colsum, dy_colsum_stride, st);
+    if (e != MI_ERR_UNSUPPORTED) return e;
+  }
   WgradArgs w;
   memset(&w, 0, sizeof(w));
   ConvArgs& a = w.c;
@@ -1538,11 +1575,11 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   {
     const int px = (a.g.lds_bytes + 1023) / 1024, py = (nvox * 64 + 1023) / 1024;
     const int64_t dyb = (int64_t)P->N * P->Do * P->Ho * P->Wo * dy_cs * 2;
-    if (use_w2 && P->KT > 1 && !scale_shift && a.g.vox == 64 &&  // (1x1 convs: the k-split path is faster on the register-staged kernel)
-        (a.x_cs & 7) == 0 && (a.Cin & 7) == 0 && (dy_cs & 7) == 0 && (P->Cout & 7) == 0 && px <= 40 &&
+    if (use_w2 && !scale_shift && a.g.vox == 64 && (a.x_cs & 7) == 0 && (a.Cin & 7) == 0 && (dy_cs & 7) == 0 && (P->Cout & 7) == 0 && px <= 40 &&
         py <= 16 && dyb < (1ll << 32)) {
       w.dy_bytes = (unsigned)dyb;
-      const size_t lds2 = (size_t)(2 * px + 2 * py) * 1024;
+      w.nbuf = (P->KT == 1 && px == 16 && py == 16) ? 4 : 2;  // 1x1: tiles are pure loads -> three tiles in flight per workgroup
+      const size_t lds2 = (size_t)(w.nbuf * (px + py)) * 1024;
       const bool geo3 = P->full27 && a.g.row == WG3_XROW && a.g.slice == WG3_XSLICE && a.g.TD == 4 && a.g.TH == 8 && a.g.TW == 8;
       static bool attr3 = false, attrg = false;
       bool& done = geo3 ? attr3 : attrg;

@@ -69,3 +69,7 @@ using namespace mi_conv;
 
 // conv27.hip: k3 s1 p1 3-D forward (flip = 0) / data gradient (flip = 1) on the 4x8x8 tile; a.g / tables as for the table-driven kernel
 int mi_launch_conv27(const ConvArgs& a, int NCB, int flip, int ntiles, int ny, hipStream_t st);
+// conv1x1.hip: 1x1x1 forward / data gradient as a streaming GEMM over voxels
+int mi_launch_conv1x1(const ConvArgs& a, int NCB, int ny, hipStream_t st);
+int mi_launch_wgrad1x1(const void* x, int x_cs, int Cin, const void* dy, int dy_cs, int Cout, int N, int64_t V, float* dw, float* colsum,
+                       int colsum_stride, hipStream_t st);

@@ -135,10 +135,12 @@ def gn(ctx: Ctx, x, name, groups, eps):
 
 
 def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addvec=None, res=None, d_addvec=None,
-         need_dx=True):
+         need_dx=True, bias_grad_like=None):
     """y = conv(act(x)) + addvec + res   (weight `name.weight`, bias folded into addvec by the caller or taken from
     `name.bias` when addvec is None).  norm: GNStats of x for the fused prologue.  d_addvec: fp32 [N, Cout] view that
-    receives the per-sample column sums of dy (time-embedding gradient) in backward."""
+    receives the per-sample column sums of dy (time-embedding gradient) in backward.  bias_grad_like: name of a conv whose
+    output gradient is THIS conv's output gradient (a shortcut conv added as `res` of that conv): its bias gradient, already
+    computed when this backward runs, is copied instead of reducing dy a second time."""
     n, d, h, w, cin = x.shape
     wt = ctx.p(name + ".weight")
     cout = wt.shape[0]
@@ -167,7 +169,11 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
             # column sums of dy come out of the wgrad kernel (one extra MFMA per k-step on the dY fragments it holds anyway):
             # per image into `d_addvec` (time-embedding gradient; the caller folds the rows into the bias gradient), or --
             # row pitch 0 -- summed over the batch straight into the bias gradient
-            plan.wgrad(xin, dy, gw, pn, ps, colsum=d_addvec if d_addvec is not None else ctx.g(name + ".bias"))
+            if bias_grad_like is not None:
+                plan.wgrad(xin, dy, gw, pn, ps)
+                ops.add_f32_(ctx.g(name + ".bias"), ctx.g(bias_grad_like + ".bias"))
+            else:
+                plan.wgrad(xin, dy, gw, pn, ps, colsum=d_addvec if d_addvec is not None else ctx.g(name + ".bias"))
             if res is not None:
                 tape.put(res, dy)
             if need_dx:

@@ -311,7 +311,7 @@ class DiffusionModelUNet(HipModule):
                    d_addvec=d_temb_all[:, off:off + cout] if d_temb_all is not None else None)
         n2 = E.gn(c, h, name + ".norm2", self.groups, self.eps)
         if name + ".skip_connection.conv.weight" in c.arena.offsets:
-            xs = E.conv(c, x, name + ".skip_connection.conv", (1, 1, 1), s1, (0, 0, 0))
+            xs = E.conv(c, x, name + ".skip_connection.conv", (1, 1, 1), s1, (0, 0, 0), bias_grad_like=name + ".conv2.conv")
         else:
             xs = x
         return E.conv(c, h, name + ".conv2.conv", k3, s1, p1, norm=n2, silu=True, res=xs)
