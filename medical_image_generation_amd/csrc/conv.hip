@@ -423,6 +423,8 @@ struct WgradArgs {
   const bf16* dy; int dy_cs;
   unsigned dy_bytes;  // size of dy for its buffer descriptor (LDS-DMA kernel)
   int nbuf;           // LDS-DMA kernel: image ring depth (2; 4 for 1x1 pairs)
+  float* cs_part;     // [nsplit][N][Cout] per-workgroup column sums (tap pairs): plain stores, folded by k_cs_reduce -- 256 workgroups
+                      // adding to the same 128-byte line with atomics serialise for tens of microseconds
   float* part;        // [nsplit][npairs][MAXTAPS? -> ntaps_of_pair][32][32] laid out by pair_off
   const int* pair_off;  // [npairs] float offset of the pair's slab inside one split's partial
   int64_t split_stride; // floats per split
@@ -685,13 +687,22 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int co = y * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (co < a.Cout) atomicAdd(w.colsum + (int64_t)img * w.colsum_stride + co, cs[e]);
+        if (co < a.Cout) {
+          if (w.cs_part && !ksplit) w.cs_part[((int64_t)split * a.N + img) * a.Cout + co] = cs[e];
+          else atomicAdd(w.colsum + (int64_t)img * w.colsum_stride + co, cs[e]);
+        }
       }
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) cs[e] = 0.f;
   };
   int cs_n = n;
+  if (cs_wave && w.cs_part && !ksplit) {  // rows of images this workgroup never reaches must read as zero
+    for (int i = lane; i < a.N * 32; i += 64) {
+      const int img = i >> 5, co = y * 32 + (i & 31);
+      if (co < a.Cout) w.cs_part[((int64_t)split * a.N + img) * a.Cout + co] = 0.f;
+    }
+  }
   Stage<NP> st;
   StageY<NPY> sy;
   stage_init<NP, NT>(st, g);
@@ -953,13 +964,22 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int co = y * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (co < a.Cout) atomicAdd(w.colsum + (int64_t)img * w.colsum_stride + co, cs[e]);
+        if (co < a.Cout) {
+          if (w.cs_part && !ksplit) w.cs_part[((int64_t)split * a.N + img) * a.Cout + co] = cs[e];
+          else atomicAdd(w.colsum + (int64_t)img * w.colsum_stride + co, cs[e]);
+        }
       }
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) cs[e] = 0.f;
   };
   int cs_n = n;
+  if (cs_wave && w.cs_part && !ksplit) {  // rows of images this workgroup never reaches must read as zero
+    for (int i = lane; i < a.N * 32; i += 64) {
+      const int img = i >> 5, co = y * 32 + (i & 31);
+      if (co < a.Cout) w.cs_part[((int64_t)split * a.N + img) * a.Cout + co] = 0.f;
+    }
+  }
   __builtin_amdgcn_s_barrier();  // prologue: tile 0 is in slot 0
   while (true) {
     if (cs_wave && n != cs_n) {
@@ -1095,6 +1115,21 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
   }
 }
 
+// colsum[n * stride + co] += sum_split cs_part[split][n][co]   (stride 0: one row for the whole batch)
+__global__ void __launch_bounds__(256) k_cs_reduce(const float* __restrict__ part, int nsplit, int N, int Cout, float* __restrict__ out, int stride) {
+  const int co = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+  if (co >= Cout) return;
+  float s0 = 0.f, s1 = 0.f;
+  int k = 0;
+  for (; k + 1 < nsplit; k += 2) {
+    s0 += part[((int64_t)k * N + n) * Cout + co];
+    s1 += part[((int64_t)(k + 1) * N + n) * Cout + co];
+  }
+  if (k < nsplit) s0 += part[((int64_t)k * N + n) * Cout + co];
+  if (stride == 0) atomicAdd(out + co, s0 + s1);  // N rows fold into one
+  else out[(int64_t)n * stride + co] += s0 + s1;
+}
+
 // ------------------------------------------------------------------------------------------------ host-side plan
 struct AxisCombo { int q, delta, t; };
 
@@ -1143,6 +1178,7 @@ struct mi_conv_plan {
   int* d_pair_off = nullptr; int* d_uitems = nullptr;
   int64_t wg_split_stride = 0; int wg_nsplit = 0, wg_nitems = 0;
   float* d_part = nullptr;
+  float* d_cspart = nullptr;  // [wg_nsplit][N][Cout] column-sum partials of the weight-gradient kernels
   bf16* d_xs = nullptr;   // space-to-depth image of x (strided convs)
   bf16* d_dxs = nullptr;  // depth image of dx
   bool strided = false;
@@ -1382,6 +1418,7 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   P->wg_nsplit = nsplit;
   if ((e = upload(P->wg_pair_off, &P->d_pair_off)) || (e = upload(P->wg_uitems, &P->d_uitems))) { mi_conv_plan_destroy(P); return e; }
   if (hipMalloc((void**)&P->d_part, (size_t)nsplit * off * 4) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
+  if (hipMalloc((void**)&P->d_cspart, (size_t)nsplit * N * Cout * 4) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
   if (P->strided) {
     size_t nb = (size_t)N * P->Dp * P->Hp * P->Wp * P->Q * Cin * 2;
     if (hipMalloc((void**)&P->d_xs, nb) != hipSuccess || hipMalloc((void**)&P->d_dxs, nb) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
@@ -1396,6 +1433,7 @@ int mi_conv_plan_destroy(mi_conv_plan* P) {
   if (P->d_pair_off) (void)hipFree(P->d_pair_off);
   if (P->d_uitems) (void)hipFree(P->d_uitems);
   if (P->d_part) (void)hipFree(P->d_part);
+  if (P->d_cspart) (void)hipFree(P->d_cspart);
   if (P->d_xs) (void)hipFree(P->d_xs);
   if (P->d_dxs) (void)hipFree(P->d_dxs);
   delete P;
@@ -1545,7 +1583,10 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   static const int dbg = env_int("MI_WGRAD_DBG", 0);
   w.dbg = dbg;
   w.colsum = dy_colsum; w.colsum_stride = dy_colsum_stride;
-  if (dy_colsum && dy_colsum_stride != 0 && dy_colsum_stride < P->Cout) return MI_ERR_BAD_ARG;  // 0: one row for the whole batch
+  static const int cs_slab = env_int("MI_CS_SLAB", 1);
+  bool cs_pairs_multi_tap = true;  // pairs that own the column sums (first chunk of a cout block) must be tap pairs, not k-split pairs
+  for (int yy = 0; yy < P->wg.ny; ++yy) cs_pairs_multi_tap = cs_pairs_multi_tap && P->wg.hdr[((size_t)yy * P->wg.nchunks) * 4 + 1] > 1;
+  w.cs_part = (cs_slab && dy_colsum && cs_pairs_multi_tap) ? P->d_cspart : nullptr;  if (dy_colsum && dy_colsum_stride != 0 && dy_colsum_stride < P->Cout) return MI_ERR_BAD_ARG;  // 0: one row for the whole batch
   const int hv = a.g.HD * a.g.HH * a.g.HW;
   const int np = (hv * 4 + 255) / 256;
   const int nvox = a.g.TD * a.g.TH * a.g.TW;
@@ -1593,6 +1634,9 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
       else hipLaunchKernelGGL(k_conv_wgrad2<false>, grid, dim3(768), lds2, st, w);
       hipLaunchKernelGGL(k_wgrad_reduce, dim3(P->wg_nitems * 16), dim3(256), 0, st, P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems,
                          P->wg_nitems, dw, P->Cout, P->Cin, P->KT);
+      if (w.cs_part)
+        hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 255) / 256, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
+                           dy_colsum_stride);
       MI_CHECK_LAUNCH();
       return 0;
     }
@@ -1609,6 +1653,9 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
 #undef MI_LAUNCH_WG_G
   hipLaunchKernelGGL(k_wgrad_reduce, dim3(P->wg_nitems * 16), dim3(256), 0, st, P->d_part, P->wg_split_stride,
                      P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT);
+  if (w.cs_part)
+    hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 255) / 256, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
+                       dy_colsum_stride);
   MI_CHECK_LAUNCH();
   return 0;
 }
