@@ -1086,48 +1086,57 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
 }
 
 // dW[co][ci][tap] += sum_split part[split][pair][ti][co_l][ci_l];  uitems[(pair, ti)] = {src_tap, co0, ci0, _}
-// block = 64 elements x 4 split-groups: each thread sums nsplit/4 slabs with 4 independent loads in flight, LDS folds the
-// 4 groups.  (One thread per element walking all slabs serially is pure load latency: 256 dependent round trips.)
+// block = 32 elements x 8 split groups: each thread sums nsplit/8 slabs with 4 independent loads in flight, LDS folds the
+// groups.  (One thread per element walking all 256 slabs serially is pure load latency.)
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, int64_t split_stride, int nsplit,
                                                       const int* __restrict__ uitems, int nitems, float* __restrict__ dw, int Co_t,
                                                       int Ci_t, int KT) {
-  __shared__ float red[4][64];
-  const int item = blockIdx.x >> 4, e = ((blockIdx.x & 15) << 6) + (threadIdx.x & 63), kg = threadIdx.x >> 6;
+  __shared__ float red[8][32];
+  const int item = blockIdx.x >> 5, e = ((blockIdx.x & 31) << 5) + (threadIdx.x & 31), kg = threadIdx.x >> 5;
   const float* p = part + (int64_t)item * 1024 + e;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int k = kg;
-  for (; k + 12 < nsplit; k += 16) {
+  for (; k + 24 < nsplit; k += 32) {
     s0 += p[(int64_t)k * split_stride];
-    s1 += p[(int64_t)(k + 4) * split_stride];
-    s2 += p[(int64_t)(k + 8) * split_stride];
-    s3 += p[(int64_t)(k + 12) * split_stride];
+    s1 += p[(int64_t)(k + 8) * split_stride];
+    s2 += p[(int64_t)(k + 16) * split_stride];
+    s3 += p[(int64_t)(k + 24) * split_stride];
   }
-  for (; k < nsplit; k += 4) s0 += p[(int64_t)k * split_stride];
-  red[kg][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  for (; k < nsplit; k += 8) s0 += p[(int64_t)k * split_stride];
+  red[kg][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (kg == 0) {
     const int* it = uitems + item * 4;
     const int tap = it[0], co = it[1] + (e >> 5), ci = it[2] + (e & 31);
     if (tap >= 0 && co < Co_t && ci < Ci_t) {
       const int l = threadIdx.x;
-      dw[((int64_t)co * Ci_t + ci) * KT + tap] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+      dw[((int64_t)co * Ci_t + ci) * KT + tap] +=
+          ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) + ((red[4][l] + red[5][l]) + (red[6][l] + red[7][l]));
     }
   }
 }
 
-// colsum[n * stride + co] += sum_split cs_part[split][n][co]   (stride 0: one row for the whole batch)
+// colsum[n * stride + co] += sum_split cs_part[split][n][co]   (stride 0: one row for the whole batch); block = 32 channels x 8 split groups
 __global__ void __launch_bounds__(256) k_cs_reduce(const float* __restrict__ part, int nsplit, int N, int Cout, float* __restrict__ out, int stride) {
-  const int co = blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-  if (co >= Cout) return;
+  __shared__ float red[8][32];
+  const int co = blockIdx.x * 32 + (threadIdx.x & 31), n = blockIdx.y, kg = threadIdx.x >> 5;
   float s0 = 0.f, s1 = 0.f;
-  int k = 0;
-  for (; k + 1 < nsplit; k += 2) {
-    s0 += part[((int64_t)k * N + n) * Cout + co];
-    s1 += part[((int64_t)(k + 1) * N + n) * Cout + co];
+  if (co < Cout) {
+    int k = kg;
+    for (; k + 8 < nsplit; k += 16) {
+      s0 += part[((int64_t)k * N + n) * Cout + co];
+      s1 += part[((int64_t)(k + 8) * N + n) * Cout + co];
+    }
+    if (k < nsplit) s0 += part[((int64_t)k * N + n) * Cout + co];
   }
-  if (k < nsplit) s0 += part[((int64_t)k * N + n) * Cout + co];
-  if (stride == 0) atomicAdd(out + co, s0 + s1);  // N rows fold into one
-  else out[(int64_t)n * stride + co] += s0 + s1;
+  red[kg][threadIdx.x & 31] = s0 + s1;
+  __syncthreads();
+  if (kg == 0 && co < Cout) {
+    const int l = threadIdx.x;
+    const float v = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) + ((red[4][l] + red[5][l]) + (red[6][l] + red[7][l]));
+    if (stride == 0) atomicAdd(out + co, v);  // N rows fold into one
+    else out[(int64_t)n * stride + co] += v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ host-side plan
@@ -1632,10 +1641,10 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
       }
       if (geo3) hipLaunchKernelGGL(k_conv_wgrad2<true>, grid, dim3(768), lds2, st, w);
       else hipLaunchKernelGGL(k_conv_wgrad2<false>, grid, dim3(768), lds2, st, w);
-      hipLaunchKernelGGL(k_wgrad_reduce, dim3(P->wg_nitems * 16), dim3(256), 0, st, P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems,
+      hipLaunchKernelGGL(k_wgrad_reduce, dim3(P->wg_nitems * 32), dim3(256), 0, st, P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems,
                          P->wg_nitems, dw, P->Cout, P->Cin, P->KT);
       if (w.cs_part)
-        hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 255) / 256, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
+        hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 31) / 32, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
                            dy_colsum_stride);
       MI_CHECK_LAUNCH();
       return 0;
@@ -1651,10 +1660,10 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   else MI_LAUNCH_WG(8);
 #undef MI_LAUNCH_WG
 #undef MI_LAUNCH_WG_G
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(P->wg_nitems * 16), dim3(256), 0, st, P->d_part, P->wg_split_stride,
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(P->wg_nitems * 32), dim3(256), 0, st, P->d_part, P->wg_split_stride,
                      P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT);
   if (w.cs_part)
-    hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 255) / 256, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
+    hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 31) / 32, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
                        dy_colsum_stride);
   MI_CHECK_LAUNCH();
   return 0;

@@ -29,6 +29,7 @@
 // (row (e&3) + 8(e>>2) + 4h <-> channel 16h + e; the permutation is applied when the weights are packed).
 // Rounding: conv + bias/temb is rounded to bf16 once (staging), the residual is added to that and rounded again -- the
 // same two roundings as the reference's autocast path (conv output in bf16, then `skip + h`, UNet:701).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "conv_common.h"
@@ -47,6 +48,8 @@ template <> struct Cfg<1> { static constexpr int GT = 9; };  // 3 groups of 9 ta
 template <> struct Cfg<2> { static constexpr int GT = 3; };  // 9 groups of 3 taps
 
 typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ unsigned long long g_c27_clk[4];  // diagnostic (MI_C27_DBG & 64): shader-clock and 100 MHz real-time ticks of workgroup 0's main loop
 
 template <int NCB>
 struct K {
@@ -301,6 +304,8 @@ __device__ __forceinline__ void compute_role(const ConvArgs& a, char* lds, int y
   __builtin_amdgcn_s_barrier();  // prologue: first halo image and weight groups 0, 1 are in LDS
   issue_frags<0, NCB, FLIP>(s.fr[0], s.bcur, s.abase);
   wait_frags<NCB>(s.fr[0]);
+  unsigned long long t0 = 0, r0 = 0;
+  if (a.dbg & 64) { t0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
   int par = 0;
   while (true) {
     seq_next(q, a, tile_step, tile_last);
@@ -320,6 +325,10 @@ __device__ __forceinline__ void compute_role(const ConvArgs& a, char* lds, int y
     if (q.ntile < 0) break;
     s.cur ^= 1;
     seq_advance(q);
+  }
+  if ((a.dbg & 64) && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    g_c27_clk[0] = t1 - t0; g_c27_clk[1] = r1 - r0;
   }
   __builtin_amdgcn_s_barrier();  // final: the last tile's staging is complete
 }
@@ -553,6 +562,12 @@ int launch27(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   }
   hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), (size_t)KK::LDS_TOTAL, st, a);
   MI_CHECK_LAUNCH();
+  if (a.dbg & 64) {  // diagnostic only: synchronises
+    unsigned long long h[4] = {0, 0, 0, 0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_c27_clk), sizeof(h));
+    if (h[1]) fprintf(stderr, "[conv27<%d,%d>] main loop: %llu shader cycles in %.1f us -> %.0f MHz\n", NCB, FLIP, h[0], h[1] / 100.0, h[0] / (h[1] / 100.0));
+  }
   return 0;
 }
 
