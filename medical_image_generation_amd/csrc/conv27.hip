@@ -40,7 +40,6 @@ namespace {
 constexpr int HROW = 640, HSLICE = 6400;   // dense halo image: 10 voxels x 64 B per row, 10 rows per slice, 6 slices
 constexpr int HALO_VOX = 600;
 constexpr int HALO_BYTES = 40960;          // image (38400 B) rounded up to 40 whole 1-KiB DMA pieces
-constexpr int HPW = 20;                    // halo pieces per halo-loader wave and image
 constexpr int RD = 3;                      // ring slots: weight groups are requested 2 groups ahead
 
 template <int NCB> struct Cfg;
@@ -61,8 +60,7 @@ struct K {
   static constexpr int RING0 = 2 * HALO_BYTES, STG0 = RING0 + RING, AV0 = STG0 + 4 * STG_WAVE;
   static constexpr int AV_WAVE = NCB * 2 * 64;  // per compute wave: bias (+ time embedding) of its accumulator channels [cb][h][16] fp32
   static constexpr int LDS_TOTAL = AV0 + 4 * AV_WAVE;
-  static constexpr int PIECES = 2 * PV;        // store-epilogue pieces per lane of a halo wave (2 slices x 64 voxels x PV / 64 lanes)
-  static constexpr int PPT = (PIECES + NG - 2) / (NG - 1);  // ... processed per tap group
+  static constexpr int PPT = (PV + NG - 2) / (NG - 1);  // store-epilogue pieces (of PV per helper wave and tile) processed per tap group
 };
 
 template <int N>
@@ -333,55 +331,37 @@ __device__ __forceinline__ void compute_role(const ConvArgs& a, char* lds, int y
   __builtin_amdgcn_s_barrier();  // final: the last tile's staging is complete
 }
 
-// ------------------------------------------------------------------------------------------------ weight-loader waves
+// ------------------------------------------------------------------------------------------------ helper waves (4-7)
+// Issuing an LDS-DMA instruction costs the SIMD ~100 cycles that its compute wave cannot use (measured: with two waves issuing all
+// weight pieces, the compute waves on those two SIMDs needed 60 cycles per MFMA instead of 32 and everybody waited for them at the
+// barriers).  So every helper wave does a quarter of everything: a quarter of each weight group, a quarter of the halo image,
+// one d-slice of the store epilogue.
+//
+// vmcnt bookkeeping of a helper (operations complete in issue order).  Per image, in program order:
+//   top 0 :  [residual loads of the tile being stored: R]  [weights of group 2]  [halo quarter of the next image: HPW]
+//   top J :  [weights of group J+2]            then (store slots 1 .. NG-2, after the barrier)  [PPT stores]
+//   top NG-1 : [PPT stores] before the wait
+// At top J the weights of group J+1 (issued at top J-1) must have landed: the only younger operations are, for J = 1, the halo
+// quarter, and for J >= 2 the stores of slot J-1 (plus, at top NG-1, the slot issued just before the wait).  Waiting for them
+// also retires everything older: the residual loads (usable from slot 1 on without any further wait) and, from top 2 on, the halo.
+constexpr int HPW = 10;  // halo pieces per helper wave and image
+
 template <int NCB>
-__device__ __forceinline__ void issue_A(const ConvArgs& a, char* lds, int y, int al, int lane, int ch, int j, int slot) {
+__device__ __forceinline__ void issue_A(const ConvArgs& a, char* lds, int y, int hl, int lane, int ch, int j, int slot) {
   using KK = K<NCB>;
   const __amdgpu_buffer_rsrc_t rw = make_rsrc(a.wpk, a.wpk_bytes);
   // fragments are packed [cout group][chunk][tap][ks][cb] and every chunk of a k3 s1 conv has all 27 taps: no table lookup
   // (a load inside the loop would be a VECTOR load -- the kernel stores to global memory -- and drain the DMA queue)
   const int wfrag = (y * a.nchunks + ch) * (27 * 2 * NCB) + j * KK::FRAGS;
 #pragma unroll
-  for (int i = 0; i < KK::FRAGS / 2; ++i) {
-    const int f = al + 2 * i;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + KK::RING0 + slot * KK::GROUP_BYTES + f * 1024), 16, lane * 16,
-                                             (wfrag + f) * 1024, 0, 0);
+  for (int i = 0; i < (KK::FRAGS + 3) / 4; ++i) {
+    const int f = hl + 4 * i;
+    if (f < KK::FRAGS)  // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void*)(lds + KK::RING0 + slot * KK::GROUP_BYTES + f * 1024), 16, lane * 16,
+                                               (wfrag + f) * 1024, 0, 0);
   }
 }
 
-template <int NCB>
-__device__ __forceinline__ void wload_role(const ConvArgs& a, char* lds, int y, int al, int lane, int tile0, int tile_step, int tile_last) {
-  using KK = K<NCB>;
-  const bool resident = a.nchunks == 1 && KK::NG <= RD;  // the ring holds every group of the only chunk: load once
-  int a_ch = 0, a_j = 0, slot = 0, issued = 0;
-  auto issue_next = [&]() {
-    if (!(resident && issued >= KK::NG)) issue_A<NCB>(a, lds, y, al, lane, a_ch, a_j, slot);
-    issued = issued < 1000 ? issued + 1 : issued;
-    slot = slot + 1 == RD ? 0 : slot + 1;
-    if (++a_j == KK::NG) { a_j = 0; a_ch = a_ch + 1 == a.nchunks ? 0 : a_ch + 1; }
-  };
-  issue_next();
-  issue_next();  // two groups ahead
-  wait_vm<0>();
-  __builtin_amdgcn_s_barrier();  // prologue
-  Seq q;
-  q.tile = tile0; q.ch = 0;
-  tile_origin(a.g, tile0, q.n, q.d0, q.h0, q.w0);
-  while (true) {
-    seq_next(q, a, tile_step, tile_last);
-    for (int j = 0; j < KK::NG; ++j) {
-      wait_vm<0>();                  // group j+1 (requested one group ago) has landed
-      __builtin_amdgcn_s_barrier();
-      issue_next();                  // group j+2 into the slot of group j-1, which every compute wave has left
-    }
-    if (q.ntile < 0) break;
-    seq_advance(q);
-  }
-  wait_vm<0>();
-  __builtin_amdgcn_s_barrier();  // final
-}
-
-// ------------------------------------------------------------------------------------------------ halo-loader / store waves
 __device__ __forceinline__ void issue_halo(const ConvArgs& a, char* lds, const int (&hp)[HPW], int hl, int buf, int valid, int n, int d0, int h0,
                                            int w0, int src_c0) {
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
@@ -393,27 +373,26 @@ __device__ __forceinline__ void issue_halo(const ConvArgs& a, char* lds, const i
     const bool ok = (valid != 0) & (pk >= 0) & ((unsigned)gd < (unsigned)a.Di) & ((unsigned)gh < (unsigned)a.Hi) & ((unsigned)gw < (unsigned)a.Wi) &
                     (c + 8 <= a.Cin);  // (bitwise: one select, no branches)
     const unsigned off = ok ? (unsigned)((((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.x_cs + c) * 2u : 0xfffffff0u;  // out of range -> zeros
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(lds + buf * HALO_BYTES + (hl + 2 * k) * 1024), 16, off, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(lds + buf * HALO_BYTES + (hl + 4 * k) * 1024), 16, off, 0, 0, 0);
   }
 }
 
-// Store epilogue of one tile, this wave's two d-slices.  Piece p (0 .. PIECES-1): slice sl = 2*hl + p / PV, 16 voxels x PV slots
-// per wave-instruction, so that consecutive lanes cover consecutive 16-byte slots of a voxel and then the next voxel along W.
+// Store epilogue of one tile, this wave's d-slice (= compute wave hl's staging tile).  Piece p (0 .. PV-1): 16 voxels x PV slots per
+// wave-instruction, so that consecutive lanes cover consecutive 16-byte slots of a voxel and then the next voxel along W.
 template <int NCB>
 struct Epi {
-  int n, d0, h0, w0;             // the tile being stored
-  int active;                    // a tile is pending
-  u32x4 res[K<NCB>::PIECES];     // residual pieces (zeros when there is none)
+  int n, d0, h0, w0;        // the tile being stored
+  int active;               // a tile is pending
+  u32x4 res[K<NCB>::PV];    // residual pieces (issued by inline asm: the compiler must not wait for them)
 };
 template <int NCB>
-__device__ __forceinline__ void epi_geometry(const Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane, int p, int& sl, int& v, int& sidx,
-                                             bool& inside, unsigned& vox) {
+__device__ __forceinline__ void epi_geometry(const Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane, int p, int& v, int& sidx, bool& inside,
+                                             unsigned& vox) {
   using KK = K<NCB>;
-  sl = 2 * hl + p / KK::PV;
-  const int q = (p % KK::PV) * 64 + lane;
+  const int q = p * 64 + lane;
   v = q / KK::PV;
   sidx = q % KK::PV;
-  const int od = e.d0 + sl, oh = e.h0 + (v >> 3), ow = e.w0 + (v & 7);
+  const int od = e.d0 + hl, oh = e.h0 + (v >> 3), ow = e.w0 + (v & 7);
   const int co = y * NCB * 32 + sidx * 8;
   inside = (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co + 8 <= a.Cout);
   vox = (unsigned)(((e.n * a.Do + od) * a.Ho + oh) * a.Wo + ow);
@@ -423,11 +402,11 @@ __device__ __forceinline__ void epi_issue_res(Epi<NCB>& e, const ConvArgs& a, in
   using KK = K<NCB>;
   const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res_bytes);
 #pragma unroll
-  for (int p = 0; p < KK::PIECES; ++p) {
-    int sl, v, sidx; bool inside; unsigned vox;
-    epi_geometry<NCB>(e, a, y, hl, lane, p, sl, v, sidx, inside, vox);
+  for (int p = 0; p < KK::PV; ++p) {
+    int v, sidx; bool inside; unsigned vox;
+    epi_geometry<NCB>(e, a, y, hl, lane, p, v, sidx, inside, vox);
     const unsigned off = inside ? (vox * (unsigned)a.res_cs + (unsigned)(y * NCB * 32 + sidx * 8)) * 2u : 0xfffffff0u;
-    e.res[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0));
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(e.res[p]) : "v"(off), "s"(rres) : "memory");
   }
 }
 template <int P0, int CNT, int NCB>
@@ -436,23 +415,24 @@ __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y, a.y_bytes);
 #pragma unroll
   for (int p = P0; p < P0 + CNT; ++p) {
-    if (p >= KK::PIECES) break;
-    int sl, v, sidx; bool inside; unsigned vox;
-    epi_geometry<NCB>(e, a, y, hl, lane, p, sl, v, sidx, inside, vox);
-    const char* stg = lds + KK::STG0 + sl * KK::STG_WAVE;
+    if (p >= KK::PV) break;
+    int v, sidx; bool inside; unsigned vox;
+    epi_geometry<NCB>(e, a, y, hl, lane, p, v, sidx, inside, vox);
+    const char* stg = lds + KK::STG0 + hl * KK::STG_WAVE;
     u32x4 raw = *(const u32x4*)(stg + v * KK::VOXP + ((sidx ^ (v & (KK::PV - 1))) * 16));
     const int co = y * NCB * 32 + sidx * 8;
     if (has_res) {
+      asm volatile("" : "+v"(e.res[p]));  // (landed: see the vmcnt bookkeeping above)
       F8 f = unpack8(raw), rr = unpack8(e.res[p]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) f.v[j] += rr.v[j];
       raw = pack8(f);
     }
-    if (vec_ok) {  // always issued (masked lanes get an out-of-range offset)
+    if (vec_ok) {  // always issued (masked lanes get an out-of-range offset): the store count is part of the vmcnt bookkeeping
       const unsigned off = inside ? (vox * (unsigned)a.y_cs + (unsigned)co) * 2u : 0xfffffff0u;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, raw), ry, (int)off, 0, 0);
     } else {  // ragged channel counts (Cout = 1, ...): element-wise
-      const int od = e.d0 + sl, oh = e.h0 + (v >> 3), ow = e.w0 + (v & 7);
+      const int od = e.d0 + hl, oh = e.h0 + (v >> 3), ow = e.w0 + (v & 7);
       if ((od < a.Do) & (oh < a.Ho) & (ow < a.Wo)) {
         F8 f = unpack8(raw);
         bf16* yp = a.y + (int64_t)vox * a.y_cs + co;
@@ -463,69 +443,87 @@ __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char
     }
   }
 }
-// pieces of tap group J (1 .. NG-1) of the image during which a tile is stored
+// pieces of store slot J (1 .. NG-1)
 template <int J, int NCB>
-__device__ __forceinline__ void epi_group(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, int j, bool has_res, bool vec_ok) {
+__device__ __forceinline__ void epi_slot(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, int j, bool has_res, bool vec_ok) {
   using KK = K<NCB>;
   if constexpr (J < KK::NG) {
     if (j == J) epi_process<(J - 1) * KK::PPT, KK::PPT, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
-    else epi_group<J + 1, NCB>(e, a, lds, y, hl, lane, j, has_res, vec_ok);
+    else epi_slot<J + 1, NCB>(e, a, lds, y, hl, lane, j, has_res, vec_ok);
   }
 }
 
 template <int NCB>
-__device__ __forceinline__ void hload_role(const ConvArgs& a, char* lds, int y, int hl, int lane, int tile0, int tile_step, int tile_last) {
+__device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y, int hl, int lane, int tile0, int tile_step, int tile_last) {
   using KK = K<NCB>;
   int hp[HPW];  // this lane's halo DMA pieces: (logical slot << 24) | (hd << 16) | (hh << 8) | hw, or -1
 #pragma unroll
   for (int k = 0; k < HPW; ++k) {
-    const int v = (hl + 2 * k) * 16 + (lane >> 2), p = lane & 3;
+    const int v = (hl + 4 * k) * 16 + (lane >> 2), p = lane & 3;
     const int hd = v / 100, rem = v - hd * 100, hh = rem / 10, hw = rem - hh * 10;
     hp[k] = v < HALO_VOX ? (((p ^ (hh & 3)) << 24) | (hd << 16) | (hh << 8) | hw) : -1;
   }
   const bool has_res = a.res != nullptr;
   const bool vec_ok = (a.y_cs & 7) == 0 && (a.Cout & 7) == 0 && a.y_bytes != 0;
+  const bool resident = a.nchunks == 1 && KK::NG <= RD;  // the ring holds every group of the only chunk: load once
+  int a_ch = 0, a_j = 0, slot = 0, issued = 0;
+  auto issue_next_A = [&]() {
+    if (!(resident && issued >= KK::NG)) issue_A<NCB>(a, lds, y, hl, lane, a_ch, a_j, slot);
+    issued = issued < 1000 ? issued + 1 : issued;
+    slot = slot + 1 == RD ? 0 : slot + 1;
+    if (++a_j == KK::NG) { a_j = 0; a_ch = a_ch + 1 == a.nchunks ? 0 : a_ch + 1; }
+  };
   Seq q;
   q.tile = tile0; q.ch = 0;
   tile_origin(a.g, tile0, q.n, q.d0, q.h0, q.w0);
   issue_halo(a, lds, hp, hl, 0, 1, q.n, q.d0, q.h0, q.w0, 0);
+  issue_next_A();
+  issue_next_A();  // two groups ahead
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();  // prologue
   Epi<NCB> e;
   e.active = 0; e.n = e.d0 = e.h0 = e.w0 = 0;
 #pragma unroll
-  for (int p = 0; p < KK::PIECES; ++p) e.res[p] = u32x4{0u, 0u, 0u, 0u};
+  for (int p = 0; p < KK::PV; ++p) e.res[p] = u32x4{0u, 0u, 0u, 0u};
   int cur = 0;
   while (true) {
     seq_next(q, a, tile_step, tile_last);
-    // group 0: the other halo buffer is free once every compute wave has passed this barrier
+    const bool epi = e.active != 0;  // wave-uniform
+    // ---- top 0
+    wait_vm<0>();  // group 1's weights are this wave's youngest operation
     __builtin_amdgcn_s_barrier();
-    if (e.active && has_res) epi_issue_res<NCB>(e, a, y, hl, lane);  // issued BEFORE the halo requests: usable without waiting for them
+    if (epi && has_res) epi_issue_res<NCB>(e, a, y, hl, lane);
+    issue_next_A();
     issue_halo(a, lds, hp, hl, cur ^ 1, q.ntile >= 0, q.nn, q.nd0, q.nh0, q.nw0, q.nch * 32);
-    // groups 1 .. NG-2: a few store pieces after each barrier; group NG-1: the last pieces BEFORE its barrier (a single-chunk
-    // tile's compute waves overwrite the staging tile right after it), then everything but those last stores must have landed
+    // ---- tops 1 .. NG-2
     for (int j = 1; j < KK::NG - 1; ++j) {
+      if (j == 1) wait_vm<HPW>();                 // younger than group 2's weights: the halo quarter
+      else if (epi && vec_ok) wait_vm<KK::PPT>();  // ... the stores of slot j-1
+      else wait_vm<0>();
       __builtin_amdgcn_s_barrier();
-      if (e.active) epi_group<1, NCB>(e, a, lds, y, hl, lane, j, has_res, vec_ok);
+      issue_next_A();
+      if (epi) epi_slot<1, NCB>(e, a, lds, y, hl, lane, j, has_res, vec_ok);
     }
-    if (e.active) {
+    // ---- top NG-1: the last store slot runs BEFORE the barrier (a single-chunk tile's compute waves overwrite the staging tile right
+    // after it); the next image's halo and group NG's weights must have landed, the stores of the last two slots may fly
+    if (epi) {
       epi_process<(KK::NG - 2) * KK::PPT, KK::PPT, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done before the compute waves may overwrite the tile
-      if (vec_ok) wait_vm<KK::PPT>(); else wait_vm<0>();  // the next halo image has landed; only the stores just issued may fly
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done
       e.active = 0;
-    } else {
-      wait_vm<0>();
     }
-    __builtin_amdgcn_s_barrier();  // group NG-1
+    if (epi && vec_ok) wait_vm<2 * KK::PPT>(); else wait_vm<0>();  // younger than group NG's weights: the stores of the last two slots
+    __builtin_amdgcn_s_barrier();
+    issue_next_A();
     if (q.ch == a.nchunks - 1 && !(a.dbg & 1)) { e.active = 1; e.n = q.n; e.d0 = q.d0; e.h0 = q.h0; e.w0 = q.w0; }
     if (q.ntile < 0) break;
     cur ^= 1;
     seq_advance(q);
   }
+  wait_vm<0>();
   __builtin_amdgcn_s_barrier();  // final: the last tile's staging is complete
   if (e.active) {
-    if (has_res) epi_issue_res<NCB>(e, a, y, hl, lane);
-    epi_process<0, KK::PIECES, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
+    if (has_res) { epi_issue_res<NCB>(e, a, y, hl, lane); wait_vm<0>(); }
+    epi_process<0, KK::PV, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
   }
   wait_vm<0>();
 }
@@ -539,8 +537,7 @@ __global__ void __launch_bounds__(512, 2) k_conv27(ConvArgs a) {
   const int tile0 = first_tile(a.ntiles, tile_last, tile_step);
   if (tile0 >= tile_last) return;  // whole workgroup, before any barrier
   if (wave < 4) compute_role<NCB, FLIP>(a, lds, y, wave, lane, tile0, tile_step, tile_last);
-  else if (wave < 6) wload_role<NCB>(a, lds, y, wave - 4, lane, tile0, tile_step, tile_last);
-  else hload_role<NCB>(a, lds, y, wave - 6, lane, tile0, tile_step, tile_last);
+  else helper_role<NCB>(a, lds, y, wave - 4, lane, tile0, tile_step, tile_last);
 }
 
 template <int NCB, int FLIP>
