@@ -867,7 +867,7 @@ __device__ __forceinline__ void dma_issue_y(const DmaPieces<MAXP>& d, const Wgra
 
 template <bool GEO3D>
 __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
-  constexpr int MAXT = 4, MAXPX = 20, MAXPY = 8;
+  constexpr int MAXT = 4, MAXPX = 10, MAXPY = 4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const ConvArgs& a = w.c;
   const Geom& g = a.g;
@@ -893,12 +893,13 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
   const bool ksplit = !GEO3D && ntaps == 1;
 
   if (wave >= 8) {  // ---------------------------------------------------------------- loader waves
-    const bool is_x = wave < 10;
-    const int first = is_x ? wave - 8 : wave - 10;
+    // every loader wave issues a quarter of the x pieces AND a quarter of the dY pieces: an LDS-DMA issue costs its SIMD ~100 cycles
+    // that the compute waves there cannot use, so the four SIMDs carry the same load
+    const int first = wave - 8;
     DmaPieces<MAXPX> dx;
     DmaPieces<MAXPY> dyp;
-    if (is_x) dma_init_x<MAXPX>(dx, g, first, 2, px, lane);
-    else dma_init_y<MAXPY>(dyp, g, first, 2, py, lane);
+    dma_init_x<MAXPX>(dx, g, first, 4, px, lane);
+    dma_init_y<MAXPY>(dyp, g, first, 4, py, lane);
     // ring of NB image pairs (w.nbuf: 2, or 4 for the 1x1 k-split pairs whose tiles are all loads and hardly any MFMA): tile i
     // lives in slot i % NB and is requested NB-1 tiles ahead.  Requests beyond the last tile are still issued (all lanes out of
     // range: zeros into a free slot) so that the counted vmcnt below stays exact.
@@ -907,10 +908,10 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
       int n, d0, h0, w0;
       const bool valid = t < w.ntiles;
       tile_origin(g, valid ? t : split, n, d0, h0, w0);
-      if (is_x) dma_issue_x<MAXPX>(dx, a, lds + slot * XB, first, 2, px, lane, n, d0, h0, w0, src_c0, valid);
-      else dma_issue_y<MAXPY>(dyp, w, lds + NB * XB + slot * YB, first, 2, py, lane, y, n, d0, h0, w0, valid);
+      dma_issue_x<MAXPX>(dx, a, lds + slot * XB, first, 4, px, lane, n, d0, h0, w0, src_c0, valid);
+      dma_issue_y<MAXPY>(dyp, w, lds + NB * XB + slot * YB, first, 4, py, lane, y, n, d0, h0, w0, valid);
     };
-    auto wait_next = [&]() {  // everything but the NB-2 youngest tiles of this wave has landed (8 pieces per tile and wave when NB = 4)
+    auto wait_next = [&]() {  // everything but the NB-2 youngest tiles of this wave has landed (4 + 4 pieces per tile and wave when NB = 4)
       if (NB == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
