@@ -1382,6 +1382,11 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   if (P->strided && (Cin % 8) != 0) { delete P; return MI_ERR_UNSUPPORTED; }
   P->ncb_fwd = Cout > 32 ? 2 : 1;
   P->ncb_dg = Cin > 32 ? 2 : 1;
+  {  // few tiles (16^3 levels): 64 output channels per workgroup would leave most CUs without a workgroup -> 32 per workgroup
+    const int64_t tiles = (int64_t)N * ((od[0] + 3) / 4) * ((od[1] + 7) / 8) * ((od[2] + 7) / 8);
+    if (od[0] > 1 && tiles * ((Cout + 63) / 64) <= 128) P->ncb_fwd = 1;
+    if (od[0] > 1 && tiles * ((Cin + 63) / 64) <= 128) P->ncb_dg = 1;
+  }
   // forward: loader reads x (or its depth image: dims Dp.., Q*Cin channels); outputs on the (Do,Ho,Wo) grid
   P->g_fwd = make_geom(2, P->Do, P->Ho, P->Wo, halo_f, N);
   static const int use27 = env_int("MI_CONV27", 1);  // 0: keep every conv on the table-driven kernel (A/B runs)
