@@ -83,6 +83,12 @@ int mi_conv_dgrad(mi_conv_plan* plan, const void* dy, int dy_cstride, void* dx, 
 int mi_conv_wgrad(mi_conv_plan* plan, const void* x, int x_cstride, const float* scale_shift, int silu, const void* dy, int dy_cstride,
                   float* dweight, float* dy_colsum, int dy_colsum_stride, hipStream_t stream);
 /* out[n*out_stride + c] (+)= sum_v x[n][v][c]  (bias / time-embedding gradients) */
+/* Linear layers (AttentionBlock to_q / to_k / to_v, UNet:379-381; AEKL:240-242): weight and bias gradient in one pass over the
+ * row-major bf16 activations: dw[out][in] (fp32, ACCUMULATED) += dy^T x, dbias[out] (optional, ACCUMULATED) += column sums of dy.
+ * Leading dimensions in elements, multiples of 8; in/out features multiples of 8. */
+int mi_linear_wgrad_bf16(const void* x, int ldx, int in_features, const void* dy, int ldy, int out_features, int64_t rows, float* dw,
+                         float* dbias, hipStream_t stream);
+
 int mi_colsum_bf16(const void* x, float* out, int out_stride, int N, int64_t V, int C, int accumulate, hipStream_t stream);
 /* tiny fp32 helpers for bias / embedding vectors: y[r][c] += x[r][c];  out[c] (+)= sum_r in[r][c] */
 int mi_add_f32_2d(const float* x, int ldx, float* y, int ldy, int rows, int cols, hipStream_t stream);

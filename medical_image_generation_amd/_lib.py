@@ -40,6 +40,7 @@ _SIGS = {
     "mi_conv_fwd": [_p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
     "mi_conv_dgrad": [_p, _p, _i, _p, _i, _p],
     "mi_conv_wgrad": [_p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p],
+    "mi_linear_wgrad_bf16": [_p, _i, _i, _p, _i, _i, _l, _p, _p, _p],
     "mi_colsum_bf16": [_p, _p, _i, _i, _l, _i, _i, _p],
     "mi_add_f32_2d": [_p, _i, _p, _i, _i, _i, _p],
     "mi_sum_rows_f32": [_p, _i, _i, _i, _p, _i, _p],

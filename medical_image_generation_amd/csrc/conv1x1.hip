@@ -346,3 +346,11 @@ int mi_launch_wgrad1x1(const void* x, int x_cs, int Cin, const void* dy, int dy_
   if (NCI == 1) return launch_w11<2, 1>(p, gy, gz, st);
   return launch_w11<2, 2>(p, gy, gz, st);
 }
+
+// Weight / bias gradient of a Linear layer y = x W^T + b on row-major bf16 activations (AttentionBlock's to_q/k/v, UNet:379-381):
+// dW[out][in] += dy^T x, db[out] += column sums of dy -- the same single-pass kernel (no transposes, no split-K GEMM).
+extern "C" int mi_linear_wgrad_bf16(const void* x, int ldx, int in_features, const void* dy, int ldy, int out_features, int64_t rows, float* dw,
+                                    float* dbias, hipStream_t st) {
+  if (!x || !dy || !dw || rows <= 0 || in_features <= 0 || out_features <= 0 || ldx < in_features || ldy < out_features) return MI_ERR_BAD_ARG;
+  return mi_launch_wgrad1x1(x, ldx, in_features, dy, ldy, out_features, 1, rows, dw, dbias, 0, st);
+}

@@ -273,12 +273,10 @@ def _attention_flash(ctx, x, name, st, xn, wqkv, qkv, b, s, c, heads, scale):
 def _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy, b, s, c):
     """Shared tail of the attention backward: projection weight/bias gradients, dx through the projections and the norm."""
     dev = x.device
-    dqkv_t = _transpose(dqkv, 3 * c, 0, 0, b * s, 3 * c, 1, 1, dev)[0]   # [3C, B*S]
-    xn_t = _transpose(xn, c, 0, 0, b * s, c, 1, 1, dev)[0]               # [C, B*S]
     gw = ctx.arena.span([f"{name}.to_{t}.weight" for t in "qkv"], ctx.arena.grad)
-    _gemm(dqkv_t, b * s, 0, 0, xn_t, b * s, 0, 0, gw, c, 0, 0, 3 * c, c, b * s, 1, 1, accumulate=True)
     gb = ctx.arena.span([f"{name}.to_{t}.bias" for t in "qkv"], ctx.arena.grad)
-    ops.colsum(dqkv.view(1, 1, 1, b * s, 3 * c), out=gb.view(1, 3 * c), accumulate=True)
+    # dW[3C, C] += dqkv^T xn and db += colsum(dqkv) in ONE pass over the two activations (no transposes, no long-K GEMM on 12 workgroups)
+    call("mi_linear_wgrad_bf16", ptr(xn), c, c, ptr(dqkv), 3 * c, 3 * c, b * s, ptr(gw), ptr(gb))
     wqkv_t = _transpose(wqkv, c, 0, 0, 3 * c, c, 1, 1, dev)[0]           # [C, 3C]
     dxn = torch.empty(x.shape, dtype=BF16, device=dev)
     _gemm(dqkv, 3 * c, 0, 0, wqkv_t, 3 * c, 0, 0, dxn, c, 0, 0, b * s, c, 3 * c, 1, 1)

@@ -73,6 +73,19 @@ def wrap_shape(fname):
 for fn in ("gn_stats", "gn_apply", "gn_bwd", "add", "concat_channels", "slice_channels", "upsample_nearest", "upsample_nearest_bwd"):
     wrap_shape(fn)
 
+_orig_gemm = engine._gemm
+
+
+def _gemm_labelled(a, lda, sa1, sa2, b, ldb, sb1, sb2, c, ldc, sc1, sc2, m, n, k, z, z2, **kw):
+    label[0] = f"m{m} n{n} k{k} z{z}"
+    try:
+        return _orig_gemm(a, lda, sa1, sa2, b, ldb, sb1, sb2, c, ldc, sc1, sc2, m, n, k, z, z2, **kw)
+    finally:
+        label[0] = None
+
+
+engine._gemm = _gemm_labelled
+
 torch.manual_seed(42)
 net = DiffusionModelUNet(**bench.C4)
 for n, p in net.named_parameters():
