@@ -150,16 +150,23 @@ __global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ p
   }
 }
 
-// y = act(x * scale + shift)
+// y = act(x * scale + shift).  The host sizes the grid so that the grid stride is a multiple of C8: a thread then keeps ONE channel
+// octet for its whole loop and its 16 scale / shift values stay in registers (reloaded only when the image index changes) --
+// per 16-byte piece the kernel issues 2 vector-memory instructions instead of 18.
 __global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int xcs, const float* __restrict__ scale_shift,
                                                  bf16* __restrict__ y, int ycs, int C8, int64_t V, int silu, int64_t total) {
   const int C = C8 * 8;
-  for (int64_t i = blockIdx.x * (int64_t)kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
-    int cg = (int)(i % C8);
-    int64_t nv = i / C8;
-    int64_t n = nv / V;
-    float sc[8], sh[8];
-    load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
+  const int64_t i0 = blockIdx.x * (int64_t)kT + threadIdx.x;
+  const int cg = (int)(i0 % C8);
+  int64_t n_cur = -1;
+  float sc[8], sh[8];
+  for (int64_t i = i0; i < total; i += (int64_t)gridDim.x * kT) {
+    const int64_t nv = i / C8;
+    const int64_t n = nv / V;
+    if (n != n_cur) {
+      load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
+      n_cur = n;
+    }
     F8 f = unpack8(*(const u32x4*)(x + nv * xcs + cg * 8));
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -255,19 +262,26 @@ __global__ void __launch_bounds__(256) k_gn_bwd_finalize(const float* __restrict
   }
 }
 
-// dx = a*du + b*x + c (+ add)
+// dx = a*du + b*x + c (+ add); grid stride a multiple of C8 as in k_gn_apply: 40 per-channel constants stay in registers
 __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                      const float* __restrict__ scale_shift, const float* __restrict__ coef,
                                                      const bf16* __restrict__ add, int acs, bf16* __restrict__ dx, int dcs, int C8,
                                                      int64_t V, int silu, int64_t total) {
   const int C = C8 * 8;
-  for (int64_t i = blockIdx.x * (int64_t)kT + threadIdx.x; i < total; i += (int64_t)gridDim.x * kT) {
-    int cg = (int)(i % C8);
-    int64_t nv = i / C8;
-    int64_t n = nv / V;
-    float sc[8], sh[8];
-    load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
-    const float* cf = coef + (n * C + cg * 8) * 3;
+  const int64_t i0 = blockIdx.x * (int64_t)kT + threadIdx.x;
+  const int cg = (int)(i0 % C8);
+  int64_t n_cur = -1;
+  float sc[8], sh[8], ca[8], cb[8], cc[8];
+  for (int64_t i = i0; i < total; i += (int64_t)gridDim.x * kT) {
+    const int64_t nv = i / C8;
+    const int64_t n = nv / V;
+    if (n != n_cur) {
+      load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
+      const float* cf = coef + (n * C + cg * 8) * 3;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { ca[j] = cf[3 * j]; cb[j] = cf[3 * j + 1]; cc[j] = cf[3 * j + 2]; }
+      n_cur = n;
+    }
     F8 fx = unpack8(*(const u32x4*)(x + nv * xcs + cg * 8));
     F8 fg = unpack8(*(const u32x4*)(g + nv * gcs + cg * 8));
     F8 o;
@@ -275,7 +289,7 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
     for (int j = 0; j < 8; ++j) {
       float du = fg.v[j];
       if (silu) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
-      o.v[j] = cf[3 * j] * du + cf[3 * j + 1] * fx.v[j] + cf[3 * j + 2];
+      o.v[j] = ca[j] * du + cb[j] * fx.v[j] + cc[j];
     }
     if (add) {
       F8 fa = unpack8(*(const u32x4*)(add + nv * acs + cg * 8));
@@ -284,6 +298,17 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
     }
     *(u32x4*)(dx + nv * dcs + cg * 8) = pack8(o);
   }
+}
+
+// grid for the streaming apply kernels: <= cap blocks, total thread count a multiple of C8 (see k_gn_apply)
+inline int64_t apply_grid(int64_t total, int C8) {
+  int64_t grid = (total + kT - 1) / kT;
+  if (grid > 256 * 16) grid = 256 * 16;
+  int m = C8;  // kT * grid % C8 == 0  <=>  grid % (C8 / gcd(C8, kT)) == 0
+  for (int a = kT, b = C8; b;) { int t = a % b; a = b; b = t; m = C8 / a; }
+  if (grid >= m) grid -= grid % m;
+  else grid = m;  // tiny tensors: a few idle blocks
+  return grid;
 }
 
 inline int64_t pick_vchunk(int64_t V) {
@@ -322,8 +347,7 @@ int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y,
                 hipStream_t st) {
   if (C <= 0 || (C & 7) || (x_cstride & 7) || (y_cstride & 7) || N <= 0 || V <= 0) return MI_ERR_BAD_ARG;
   int64_t total = (int64_t)N * V * (C / 8);
-  int64_t grid = (total + kT - 1) / kT;
-  if (grid > 256 * 16) grid = 256 * 16;
+  int64_t grid = apply_grid(total, C / 8);
   hipLaunchKernelGGL(k_gn_apply, dim3((int)grid), dim3(kT), 0, st, (const bf16*)x, x_cstride, scale_shift, (bf16*)y, y_cstride, C / 8, V,
                      silu, total);
   MI_CHECK_LAUNCH();
@@ -344,8 +368,7 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(N * G), dim3(256), sizeof(float) * 2 * (size_t)(C / G), st, (const float*)workspace, chunks, C,
                      G, V, gamma, mean_rstd, coef, dgamma, dbeta);
   int64_t total = (int64_t)N * V * (C / 8);
-  int64_t grid = (total + kT - 1) / kT;
-  if (grid > 256 * 16) grid = 256 * 16;
+  int64_t grid = apply_grid(total, C / 8);
   hipLaunchKernelGGL(k_gn_bwd_apply, dim3((int)grid), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift,
                      coef, (const bf16*)add, add_cstride, (bf16*)dx, dx_cstride, C / 8, V, silu, total);
   MI_CHECK_LAUNCH();
