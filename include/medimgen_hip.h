@@ -70,6 +70,14 @@ int mi_conv_plan_destroy(mi_conv_plan* plan);
 int mi_conv_plan_out_dims(const mi_conv_plan* plan, int* dims3);
 /* fp32 master weight (torch layout) -> packed bf16 MFMA fragments for forward and data-gradient; call after every update */
 int mi_conv_pack_weights(mi_conv_plan* plan, const float* weight, hipStream_t stream);
+/* All convs of a network re-packed in ONE launch (weights change every optimizer step; per-conv launches are mostly launch
+ * floor).  plans[i] / weights[i] as for mi_conv_pack_weights; the weight pointers must stay valid (they are the fp32 master
+ * parameters).  create/destroy are not stream operations (device allocation + copy): call them outside graph capture. */
+typedef struct mi_pack_batch mi_pack_batch;
+int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, const float* const* weights, int n);
+int mi_conv_pack_batch_run(mi_pack_batch* batch, hipStream_t stream);
+int mi_conv_pack_batch_destroy(mi_pack_batch* batch);
+
 /* y = conv(act(x)) + addvec + res;  act = GroupNorm affine (+SiLU) applied on the fly when scale_shift != NULL;
  * addvec: fp32 [Cout] (addvec_stride 0: bias) or N rows of pitch addvec_stride (bias + time-embedding projection, UNet:692-695) */
 int mi_conv_fwd(mi_conv_plan* plan, const void* x, int x_cstride, const float* scale_shift, int silu, const float* addvec,

@@ -37,6 +37,9 @@ _SIGS = {
     "mi_conv_plan_destroy": [_p],
     "mi_conv_plan_out_dims": [_p, C.POINTER(_i)],
     "mi_conv_pack_weights": [_p, _p, _p],
+    "mi_conv_pack_batch_create": [C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), _i],
+    "mi_conv_pack_batch_run": [_p, _p],
+    "mi_conv_pack_batch_destroy": [_p],
     "mi_conv_fwd": [_p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
     "mi_conv_dgrad": [_p, _p, _i, _p, _i, _p],
     "mi_conv_wgrad": [_p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p],

@@ -1058,11 +1058,10 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
 // ------------------------------------------------------------------------------------------------ weight pack / unpack
 // frag_items[f] = {src_tap, co0, ci0, flags}: fragment f holds A[row = co0 + r][k = ci0 + 8h + j] (kernel channel indices);
 // torch weight W[Co_t][Ci_t][KT]; flags bit0: transposed (kernel-out = torch-in), i.e. dgrad.
-__global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, u32x4* __restrict__ out,
-                                                      const int* __restrict__ items, int nfrags, u32x4* __restrict__ out2,
-                                                      const int* __restrict__ items2, int nfrags2, int Co_t, int Ci_t, int KT) {
-  // one launch packs BOTH fragment tables of a conv (forward, then data-gradient)
-  int gid = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_one(const float* __restrict__ w, u32x4* __restrict__ out, const int* __restrict__ items, int nfrags,
+                                         u32x4* __restrict__ out2, const int* __restrict__ items2, int nfrags2, int Co_t, int Ci_t, int KT,
+                                         int gid) {
+  // one conv: BOTH fragment tables (forward, then data-gradient)
   int f = gid >> 6, lane = gid & 63;
   if (f >= nfrags) {
     f -= nfrags;
@@ -1085,36 +1084,69 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
   }
   out[gid] = pack8(v);
 }
+__global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, u32x4* __restrict__ out,
+                                                      const int* __restrict__ items, int nfrags, u32x4* __restrict__ out2,
+                                                      const int* __restrict__ items2, int nfrags2, int Co_t, int Ci_t, int KT) {
+  pack_one(w, out, items, nfrags, out2, items2, nfrags2, Co_t, Ci_t, KT, blockIdx.x * 256 + threadIdx.x);
+}
+// every conv of a network in ONE launch (the per-conv launches are mostly launch floor: 67 convs, ~10 us each)
+struct PackDesc {
+  const float* w; u32x4* out; const int* items; u32x4* out2; const int* items2;
+  int nfrags, nfrags2, Co_t, Ci_t, KT;
+  int block0;  // first block of this conv
+};
+__global__ void __launch_bounds__(256) k_pack_batch(const PackDesc* __restrict__ descs, int n) {
+  int lo = 0, hi = n - 1;  // last descriptor with block0 <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const PackDesc d = descs[lo];
+  pack_one(d.w, d.out, d.items, d.nfrags, d.out2, d.items2, d.nfrags2, d.Co_t, d.Ci_t, d.KT, ((int)blockIdx.x - d.block0) * 256 + threadIdx.x);
+}
 
 // dW[co][ci][tap] += sum_split part[split][pair][ti][co_l][ci_l];  uitems[(pair, ti)] = {src_tap, co0, ci0, _}
-// block = 32 elements x 8 split groups: each thread sums nsplit/8 slabs with 4 independent loads in flight, LDS folds the
-// groups.  (One thread per element walking all 256 slabs serially is pure load latency.)
+// block = (256 / KG) elements x KG split groups: each thread sums nsplit/KG slabs with 4 independent loads in flight, LDS folds
+// the groups.  (One thread per element walking all 256 slabs serially is pure load latency; with few slabs -- wide layers --
+// fewer groups keep the block count and the idle threads down.)
+template <int KG>
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, int64_t split_stride, int nsplit,
                                                       const int* __restrict__ uitems, int nitems, float* __restrict__ dw, int Co_t,
                                                       int Ci_t, int KT) {
-  __shared__ float red[8][32];
-  const int item = blockIdx.x >> 5, e = ((blockIdx.x & 31) << 5) + (threadIdx.x & 31), kg = threadIdx.x >> 5;
+  constexpr int EL = 256 / KG, BPI = 1024 / EL;  // elements per block, blocks per 32x32 item
+  __shared__ float red[KG][EL];
+  const int item = blockIdx.x / BPI, l = threadIdx.x % EL, e = (blockIdx.x % BPI) * EL + l, kg = threadIdx.x / EL;
   const float* p = part + (int64_t)item * 1024 + e;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int k = kg;
-  for (; k + 24 < nsplit; k += 32) {
+  for (; k + 3 * KG < nsplit; k += 4 * KG) {
     s0 += p[(int64_t)k * split_stride];
-    s1 += p[(int64_t)(k + 8) * split_stride];
-    s2 += p[(int64_t)(k + 16) * split_stride];
-    s3 += p[(int64_t)(k + 24) * split_stride];
+    s1 += p[(int64_t)(k + KG) * split_stride];
+    s2 += p[(int64_t)(k + 2 * KG) * split_stride];
+    s3 += p[(int64_t)(k + 3 * KG) * split_stride];
   }
-  for (; k < nsplit; k += 8) s0 += p[(int64_t)k * split_stride];
-  red[kg][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
+  for (; k < nsplit; k += KG) s0 += p[(int64_t)k * split_stride];
+  red[kg][l] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (kg == 0) {
     const int* it = uitems + item * 4;
     const int tap = it[0], co = it[1] + (e >> 5), ci = it[2] + (e & 31);
     if (tap >= 0 && co < Co_t && ci < Ci_t) {
-      const int l = threadIdx.x;
-      dw[((int64_t)co * Ci_t + ci) * KT + tap] +=
-          ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) + ((red[4][l] + red[5][l]) + (red[6][l] + red[7][l]));
+      float v = 0.f;
+#pragma unroll
+      for (int g2 = 0; g2 < KG; ++g2) v += red[g2][l];
+      dw[((int64_t)co * Ci_t + ci) * KT + tap] += v;
     }
   }
+}
+inline void launch_wgrad_reduce(const float* part, int64_t split_stride, int nsplit, const int* uitems, int nitems, float* dw, int Co_t, int Ci_t,
+                                int KT, hipStream_t st) {
+  if (nsplit >= 32)
+    hipLaunchKernelGGL(k_wgrad_reduce<8>, dim3(nitems * 32), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT);
+  else if (nsplit >= 8)
+    hipLaunchKernelGGL(k_wgrad_reduce<4>, dim3(nitems * 16), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT);
+  else
+    hipLaunchKernelGGL(k_wgrad_reduce<1>, dim3(nitems * 4), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT);
 }
 
 // colsum[n * stride + co] += sum_split cs_part[split][n][co]   (stride 0: one row for the whole batch); block = 32 channels x 8 split groups
@@ -1470,6 +1502,44 @@ int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
   return 0;
 }
 
+struct mi_pack_batch {
+  PackDesc* d_descs = nullptr;
+  int n = 0, nblocks = 0;
+};
+int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, const float* const* weights, int n) {
+  if (!out || !plans || !weights || n <= 0) return MI_ERR_BAD_ARG;
+  std::vector<PackDesc> h((size_t)n);
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const mi_conv_plan* P = plans[i];
+    if (!P || !weights[i]) return MI_ERR_BAD_ARG;
+    PackDesc& d = h[(size_t)i];
+    d.w = weights[i]; d.out = P->fwd.d_wpk; d.items = P->fwd.d_items; d.out2 = P->dg.d_wpk; d.items2 = P->dg.d_items;
+    d.nfrags = P->fwd.nfrags; d.nfrags2 = P->dg.nfrags; d.Co_t = P->Cout; d.Ci_t = P->Cin; d.KT = P->KT;
+    d.block0 = blocks;
+    blocks += ((P->fwd.nfrags + P->dg.nfrags) * 64 + 255) / 256;
+  }
+  mi_pack_batch* B = new mi_pack_batch();
+  B->n = n; B->nblocks = blocks;
+  if (hipMalloc((void**)&B->d_descs, sizeof(PackDesc) * (size_t)n) != hipSuccess) { delete B; return (int)hipErrorOutOfMemory; }
+  hipError_t e = hipMemcpy(B->d_descs, h.data(), sizeof(PackDesc) * (size_t)n, hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(B->d_descs); delete B; return (int)e; }
+  *out = B;
+  return 0;
+}
+int mi_conv_pack_batch_run(mi_pack_batch* B, hipStream_t st) {
+  if (!B) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_pack_batch, dim3(B->nblocks), dim3(256), 0, st, B->d_descs, B->n);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
+  if (!B) return 0;
+  if (B->d_descs) (void)hipFree(B->d_descs);
+  delete B;
+  return 0;
+}
+
 int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const float* addvec, int addvec_stride,
                 const void* res, int res_cs, void* y, int y_cs, hipStream_t st) {
   if (!P || !x || !y || x_cs < P->Cin || y_cs < P->Cout) return MI_ERR_BAD_ARG;
@@ -1647,8 +1717,7 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
       }
       if (geo3) hipLaunchKernelGGL(k_conv_wgrad2<true>, grid, dim3(768), lds2, st, w);
       else hipLaunchKernelGGL(k_conv_wgrad2<false>, grid, dim3(768), lds2, st, w);
-      hipLaunchKernelGGL(k_wgrad_reduce, dim3(P->wg_nitems * 32), dim3(256), 0, st, P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems,
-                         P->wg_nitems, dw, P->Cout, P->Cin, P->KT);
+      launch_wgrad_reduce(P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT, st);
       if (w.cs_part)
         hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 31) / 32, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
                            dy_colsum_stride);
@@ -1666,8 +1735,7 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   else MI_LAUNCH_WG(8);
 #undef MI_LAUNCH_WG
 #undef MI_LAUNCH_WG_G
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(P->wg_nitems * 32), dim3(256), 0, st, P->d_part, P->wg_split_stride,
-                     P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT);
+  launch_wgrad_reduce(P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT, st);
   if (w.cs_part)
     hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 31) / 32, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
                        dy_colsum_stride);

@@ -106,10 +106,10 @@ class Tape:
 class Ctx:
     """One forward/backward of one network: parameter views, plan cache, tape."""
 
-    def __init__(self, arena: ParamArena, plans: dict, grad_enabled=True):
+    def __init__(self, arena: ParamArena, plans: dict, grad_enabled=True, prepacked=()):
         self.arena, self.plans = arena, plans
         self.tape = Tape() if grad_enabled else None
-        self.packed = set()
+        self.packed = set(prepacked)  # plan keys whose weights are already packed for this pass (PackBatch.run)
         # algorithmic matmul-class flops of this pass (2*MACs; torch.utils.flop_counter convention, SURVEY 8d)
         self.flops_fwd = 0
         self.flops_bwd = 0
@@ -124,6 +124,33 @@ class Ctx:
 
     def g(self, name):
         return self.arena.gview(name)
+
+
+class PackBatch:
+    """Every conv plan of a network re-packed by ONE kernel launch (the weights change every optimizer step; 67 per-conv
+    launches are mostly launch floor).  Built once all plans exist, i.e. after a first pass."""
+
+    def __init__(self, arena: ParamArena, plans: dict):
+        import ctypes as C
+        self.keys = tuple(plans)
+        n = len(self.keys)
+        plan_arr = (C.c_void_p * n)(*[plans[k].handle for k in self.keys])
+        w_arr = (C.c_void_p * n)(*[arena.view(k[0] + ".weight").data_ptr() for k in self.keys])
+        h = C.c_void_p()
+        _lib.call_raw("mi_conv_pack_batch_create", C.byref(h), plan_arr, w_arr, n)
+        self.handle = h
+
+    def run(self):
+        call("mi_conv_pack_batch_run", self.handle)
+        return self.keys
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                _lib.call_raw("mi_conv_pack_batch_destroy", self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 # --------------------------------------------------------------------------------------------- ops

@@ -83,7 +83,7 @@ class DDPMTrainer:
         dims = (1,) * (3 - sd) + sp
         x_t = torch.empty((n,) + dims + (c,), dtype=torch.bfloat16, device=x0.device)
         call("mi_qsample", ptr(x0), ptr(noise), ptr(self.schedule.sqrt_acp), ptr(self.schedule.sqrt_1macp), ptr(timesteps), ptr(x_t), n, c, v)
-        ctx = E.Ctx(a, m._plans, grad_enabled=True)
+        ctx = E.Ctx(a, m._plans, grad_enabled=True, prepacked=m.pack_all())
         pred = m._run(ctx, x_t, timesteps, need_dx=False)
         dpred = torch.empty_like(pred)
         call("mi_mse_fwd_bwd", ptr(pred), ptr(noise), ptr(dpred), ptr(self.loss), n, pred.shape[-1], v, 1.0)

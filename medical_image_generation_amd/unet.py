@@ -109,6 +109,7 @@ class HipModule(nn.Module):
         self._entries = arena_order(spec.order, groups)
         self._arena = None
         self._plans = {}
+        self._packb = None
 
     def arena(self, device) -> E.ParamArena:
         """(Re)bind every nn.Parameter to a view of one flat device buffer; idempotent while nothing moved."""
@@ -123,10 +124,24 @@ class HipModule(nn.Module):
                 params[name].data = v
             self._arena = a
             self._plans = {}
+            self._packb = None
         return a
+
+    def pack_all(self):
+        """Re-pack every conv's weights in one launch; returns the plan keys it covered (empty before the plans exist).
+        Plans created later (another input shape) are packed individually by engine.conv and join the batch next time."""
+        if not self._plans or self._arena is None:
+            return ()
+        pb = getattr(self, "_packb", None)
+        if pb is None or len(pb.keys) != len(self._plans):
+            if torch.cuda.is_current_stream_capturing():
+                return () if pb is None else pb.run()
+            pb = self._packb = E.PackBatch(self._arena, self._plans)
+        return pb.run()
 
     def _apply(self, fn, *args, **kwargs):  # .to() / .cuda() / .float(): parameters move, the arena is rebuilt lazily
         self._arena = None
+        self._packb = None
         return super()._apply(fn, *args, **kwargs)
 
 
@@ -138,7 +153,7 @@ class _NetFn(torch.autograd.Function):
         dev = x.device
         ctx.set_materialize_grads(False)  # unused outputs (e.g. z_sigma) arrive as None, not as zero tensors
         arena = module.arena(dev)
-        c = E.Ctx(arena, module._plans, grad_enabled=grad_enabled)  # (autograd disables grad mode inside forward)
+        c = E.Ctx(arena, module._plans, grad_enabled=grad_enabled, prepacked=module.pack_all())  # (autograd disables grad mode inside forward)
         need_dx = bool(grad_enabled and ctx.needs_input_grad[4])
         outs_cl, extra = runner(c, x, need_dx)
         ctx.c, ctx.module, ctx.outs_cl, ctx.need_dx, ctx.extra = c, module, outs_cl, need_dx, extra
