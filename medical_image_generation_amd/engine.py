@@ -162,7 +162,7 @@ def gn(ctx: Ctx, x, name, groups, eps):
 
 
 def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addvec=None, res=None, d_addvec=None,
-         need_dx=True, bias_grad_like=None):
+         need_dx=True, bias_grad_like=None, out=None):
     """y = conv(act(x)) + addvec + res   (weight `name.weight`, bias folded into addvec by the caller or taken from
     `name.bias` when addvec is None).  norm: GNStats of x for the fused prologue.  d_addvec: fp32 [N, Cout] view that
     receives the per-sample column sums of dy (time-embedding gradient) in backward.  bias_grad_like: name of a conv whose
@@ -183,7 +183,7 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
         xin, pn, ps = ops.gn_apply(x, norm, silu), None, False
     else:
         xin, pn, ps = x, norm, silu
-    y = plan.fwd(xin, pn, ps, addvec=av, res=res)
+    y = plan.fwd(xin, pn, ps, addvec=av, res=res, out=out)  # out: channel-slice view of the consumer's concat buffer
     ctx.count(2 * y.numel() * cin * math.prod(kernel), dgrad=need_dx)
     if ctx.tape is not None:
         tape = ctx.tape
@@ -232,8 +232,23 @@ def upsample(ctx: Ctx, x, factors):
     return y
 
 
-def concat(ctx: Ctx, a, b):
-    y = ops.concat_channels(a, b)
+def concat_buffer(a_shape, ca, cb, device):
+    """Allocate the [.., ca + cb] buffer of an upcoming `concat(a, b)` and return (buffer, view of its first ca channels): the
+    producer of `a` writes there directly (conv `out=`), so that half of the concatenation costs nothing."""
+    buf = torch.empty(tuple(a_shape[:-1]) + (ca + cb,), dtype=BF16, device=device)
+    return buf, buf[..., :ca]
+
+
+def concat(ctx: Ctx, a, b, buf=None):
+    """torch.cat([a, b], channel axis) (UNet:1263, 1377, 1504).  buf: buffer from concat_buffer whose first channels ARE `a`
+    (then only b is copied); in backward d(a) is then a channel-slice VIEW of d(cat), not a copy."""
+    in_place = buf is not None and a.data_ptr() == buf.data_ptr()
+    if in_place:
+        n, v, cb_ = a.shape[0], a.shape[1] * a.shape[2] * a.shape[3], b.shape[-1]
+        call("mi_copy_channels", ptr(b), ops._cs(b), 0, ptr(buf), buf.shape[-1], a.shape[-1], cb_, n * v)
+        y = buf
+    else:
+        y = ops.concat_channels(a, b)
     if ctx.tape is not None:
         tape = ctx.tape
         ca, cb = a.shape[-1], b.shape[-1]
@@ -241,7 +256,12 @@ def concat(ctx: Ctx, a, b):
         def bwd():
             dy = tape.take(y)
             if dy is not None:
-                tape.put(a, ops.slice_channels(dy, 0, ca))
+                if in_place and id(a) not in tape.grads:  # sole consumer of `a`: hand the slice over as a strided view
+                    tape.grads[id(a)] = dy[..., :ca]
+                    tape.keep.append(a)
+                    tape.keep.append(dy)
+                else:
+                    tape.put(a, ops.slice_channels(dy, 0, ca))
                 tape.put(b, ops.slice_channels(dy, ca, cb))
 
         tape.record(bwd)

@@ -167,16 +167,22 @@ class ConvPlan:
         assert weight_f32.dtype == F32 and weight_f32.is_contiguous()
         call("mi_conv_pack_weights", self.handle, ptr(weight_f32))
 
-    def fwd(self, x, st: GNStats | None = None, silu=False, addvec=None, res=None):
+    def fwd(self, x, st: GNStats | None = None, silu=False, addvec=None, res=None, out=None):
+        """out: optional destination, a channel-slice view [N, D, H, W, Cout] of a wider channels-last buffer (the conv writes
+        straight into the skip-concat buffer of its consumer instead of being copied there)."""
         n, d, h, w, c = x.shape
         assert (n, (d, h, w), c) == (self.n, self.dims, self.cin), f"plan/input mismatch {x.shape} vs {self.n, self.dims, self.cin}"
-        y = torch.empty((n,) + self.out_dims + (self.cout,), dtype=BF16, device=x.device)
+        if out is None:
+            y = torch.empty((n,) + self.out_dims + (self.cout,), dtype=BF16, device=x.device)
+        else:
+            assert out.shape == (n,) + self.out_dims + (self.cout,) and out.dtype == BF16
+            y = out
         av_stride = 0
         if addvec is not None and addvec.dim() == 2:  # [N, Cout] rows, possibly a column slice of a wider matrix
             assert addvec.shape == (n, self.cout) and addvec.stride(1) == 1
             av_stride = addvec.stride(0)
         call("mi_conv_fwd", self.handle, ptr(x), _cs(x), ptr(st.scale_shift) if st is not None else None, int(silu), ptr(addvec), av_stride,
-             ptr(res), _cs(res) if res is not None else 0, ptr(y), self.cout)
+             ptr(res), _cs(res) if res is not None else 0, ptr(y), _cs(y))
         return y
 
     def dgrad(self, dy):

@@ -316,8 +316,9 @@ class DiffusionModelUNet(HipModule):
         self._temb_total = off
 
     # ------------------------------------------------------------------------------------------ engine forward
-    def _resnet(self, c, x, name, temb_all, d_temb_all):
-        """ResnetBlock.forward (UNet:674-701) as 2 stats passes + 3 fused convs."""
+    def _resnet(self, c, x, name, temb_all, d_temb_all, out=None):
+        """ResnetBlock.forward (UNet:674-701) as 2 stats passes + 3 fused convs.  out: where conv2 writes the block's result (the
+        first channels of the next skip-concat buffer)."""
         cout = c.p(name + ".conv1.conv.weight").shape[0]
         off = self._temb_off[name]
         k3, s1, p1 = (1,) * (3 - self.spatial_dims) + (3,) * self.spatial_dims, (1, 1, 1), (0,) * (3 - self.spatial_dims) + (1,) * self.spatial_dims
@@ -329,7 +330,7 @@ class DiffusionModelUNet(HipModule):
             xs = E.conv(c, x, name + ".skip_connection.conv", (1, 1, 1), s1, (0, 0, 0), bias_grad_like=name + ".conv2.conv")
         else:
             xs = x
-        return E.conv(c, h, name + ".conv2.conv", k3, s1, p1, norm=n2, silu=True, res=xs)
+        return E.conv(c, h, name + ".conv2.conv", k3, s1, p1, norm=n2, silu=True, res=xs, out=out)
 
     def _heads(self, ch, nhc):
         return ch // nhc if nhc is not None else 1
@@ -377,19 +378,30 @@ class DiffusionModelUNet(HipModule):
                 skips.append(h)
         h = self._resnet(c, h, "middle_block.resnet_1", temb_all, d_temb_all)
         h = E.attention(c, h, "middle_block.attention", self.groups, self.eps, self._heads(ch[-1], self.num_head_channels[-1]))
-        h = self._resnet(c, h, "middle_block.resnet_2", temb_all, d_temb_all)
+        # Whatever feeds a skip concatenation (UNet:1263, 1377, 1504) is written by its producing conv straight into the first
+        # channels of the concat buffer: only the skip half is copied, and in backward d(producer output) is a view of d(cat).
+        def cat_buffer(ca):
+            return E.concat_buffer(skips[-1].shape, ca, skips[-1].shape[-1], dev)
+
+        pending, view = cat_buffer(ch[-1])
+        h = self._resnet(c, h, "middle_block.resnet_2", temb_all, d_temb_all, out=view)
         rch, rnrb = list(reversed(ch)), list(reversed(self.num_res_blocks))
         ratt, rnhc = list(reversed(self.attention_levels)), list(reversed(self.num_head_channels))
         rs, rp = list(reversed(self._s)), list(reversed(self._p))
         for i in range(L):
-            for j in range(rnrb[i] + 1):
-                h = E.concat(c, h, skips.pop())
-                h = self._resnet(c, h, f"up_blocks.{i}.resnets.{j}", temb_all, d_temb_all)
+            n_res = rnrb[i] + 1
+            for j in range(n_res):
+                h = E.concat(c, h, skips.pop(), buf=pending)
+                pending, view = (None, None)
+                if j < n_res - 1 and not ratt[i]:  # this resnet's output is the next concat's first half
+                    pending, view = cat_buffer(rch[i])
+                h = self._resnet(c, h, f"up_blocks.{i}.resnets.{j}", temb_all, d_temb_all, out=view)
                 if ratt[i]:
                     h = E.attention(c, h, f"up_blocks.{i}.attentions.{j}", self.groups, self.eps, self._heads(rch[i], rnhc[i]))
             if i != L - 1:  # Upsample.forward (UNet:569-588): nearest x stride, then k3 conv with the LEVEL's padding
                 h = E.upsample(c, h, rs[i])
-                h = E.conv(c, h, f"up_blocks.{i}.upsampler.conv.conv", k3, (1, 1, 1), rp[i])
+                pending, view = cat_buffer(rch[i])
+                h = E.conv(c, h, f"up_blocks.{i}.upsampler.conv.conv", k3, (1, 1, 1), rp[i], out=view)
         no = E.gn(c, h, "out.0", self.groups, self.eps)
         p1 = (0,) * (3 - sd) + (1,) * sd
         return E.conv(c, h, "out.2.conv", k3, (1, 1, 1), p1, norm=no, silu=True)
