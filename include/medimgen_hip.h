@@ -137,6 +137,16 @@ int mi_qsample(const float* x0, const float* noise, const float* sqrt_alphas_cum
 int mi_mse_fwd_bwd(const void* pred, const float* target, void* dpred, float* loss, int N, int C, int64_t V, float grad_scale,
                    hipStream_t stream);
 
+/* AutoencoderKL train-step glue (T-AE:406-435, 68-72; AEKL:786-787), channels-last bf16 activations, fp32 NCDHW host-layout
+ * targets / noise: mean absolute error + gradient (loss zeroed first unless accumulate), and the reparameterisation
+ * z = mu + eps * sigma fused with the KL term (*loss += kl_weight * 0.5 * sum(mu^2 + sigma^2 - log sigma^2 - 1) / N) and
+ * its backward (dmu = dz + kl_weight/N * mu, dsigma = dz * eps + kl_weight/N * (sigma - 1/sigma)). */
+int mi_l1_fwd_bwd(const void* pred, const float* target, void* dpred, float* loss, int N, int C, int64_t V, int accumulate, hipStream_t stream);
+int mi_reparam_kl_fwd(const void* mu, const void* sigma, const float* eps, void* z, float* loss, int N, int C, int64_t V, float kl_weight,
+                      hipStream_t stream);
+int mi_reparam_kl_bwd(const void* mu, const void* sigma, const float* eps, const void* dz, void* dmu, void* dsigma, int N, int C, int64_t V,
+                      float kl_weight, hipStream_t stream);
+
 /* ---- clip_grad_norm_ (T-LDM:177, T-DDPM:196, T-AE:393,431) + torch.optim.Adam / AdamW (T-LDM:121, T-AE:470, T-DDPM:383)
  *      over the flat fp32 parameter arena; step counter and squared norm stay on the device ------------------------------- */
 int mi_sumsq_f32(const float* x, int64_t n, float* out, int accumulate, hipStream_t stream);

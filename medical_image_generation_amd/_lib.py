@@ -62,6 +62,9 @@ _SIGS = {
     "mi_logvar_to_sigma_bwd": [_p, _p, _p, _p, _l, _p],
     "mi_qsample": [_p, _p, _p, _p, _p, _p, _i, _i, _l, _p],
     "mi_mse_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _f, _p],
+    "mi_l1_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _i, _p],
+    "mi_reparam_kl_fwd": [_p, _p, _p, _p, _p, _i, _i, _l, _f, _p],
+    "mi_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _l, _f, _p],
     "mi_sumsq_f32": [_p, _l, _p, _i, _p],
     "mi_clip_grad_by_norm": [_p, _l, _p, _f, _p],
     "mi_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _p, _p],

@@ -166,6 +166,55 @@ __global__ void k_mse(const bf16* __restrict__ pred, const float* __restrict__ t
   if (threadIdx.x == 0) atomicAdd(loss_sum, s * inv_numel);
 }
 
+// loss = mean(|pred - target|) (F.l1_loss, T-AE:414); dpred = sign(pred - target) / numel.  Same layouts as k_mse.
+__global__ void k_l1(const bf16* __restrict__ pred, const float* __restrict__ target, bf16* __restrict__ dpred, float* __restrict__ loss_sum,
+                     int C, int64_t V, int64_t total, float inv_numel) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t n = i / V, v = i - n * V;
+    for (int c = 0; c < C; ++c) {
+      float d = bf2f(pred[i * C + c]) - target[(n * C + c) * V + v];
+      acc += fabsf(d);
+      if (dpred) dpred[i * C + c] = f2bf(d > 0.f ? inv_numel : (d < 0.f ? -inv_numel : 0.f));
+    }
+  }
+  float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, s * inv_numel);
+}
+
+// AutoencoderKL.sampling (AEKL:786-787) + AutoEncoder.get_kl_loss (T-AE:68-72) on channels-last bf16 latents:
+//   z = mu + eps * sigma;   kl = 0.5 * sum(mu^2 + sigma^2 - log(sigma^2) - 1) / B;   *loss += kl_weight * kl
+// eps is fp32 NCDHW (torch.randn_like layout), n = N * V voxels, C latent channels.
+__global__ void k_reparam_kl_fwd(const bf16* __restrict__ mu, const bf16* __restrict__ sigma, const float* __restrict__ eps,
+                                 bf16* __restrict__ z, float* __restrict__ loss, int C, int64_t V, int64_t total, float klw_over_b) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t n = i / V, v = i - n * V;
+    for (int c = 0; c < C; ++c) {
+      const float m = bf2f(mu[i * C + c]), sg = bf2f(sigma[i * C + c]);
+      z[i * C + c] = f2bf(m + eps[(n * C + c) * V + v] * sg);
+      acc += 0.5f * (m * m + sg * sg - logf(sg * sg) - 1.f);
+    }
+  }
+  float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, s * klw_over_b);
+}
+// dmu = dz + klw/B * mu;   dsigma = dz * eps + klw/B * (sigma - 1/sigma)
+__global__ void k_reparam_kl_bwd(const bf16* __restrict__ mu, const bf16* __restrict__ sigma, const float* __restrict__ eps,
+                                 const bf16* __restrict__ dz, bf16* __restrict__ dmu, bf16* __restrict__ dsigma, int C, int64_t V,
+                                 int64_t total, float klw_over_b) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t n = i / V, v = i - n * V;
+    for (int c = 0; c < C; ++c) {
+      const float m = bf2f(mu[i * C + c]), sg = bf2f(sigma[i * C + c]), g = bf2f(dz[i * C + c]);
+      dmu[i * C + c] = f2bf(g + klw_over_b * m);
+      dsigma[i * C + c] = f2bf(g * eps[(n * C + c) * V + v] + klw_over_b * (sg - 1.f / sg));
+    }
+  }
+}
+
 // ---------------------------------------------------------------- sinusoidal timestep embedding (UNet:461-485)
 __global__ void k_timestep_embedding(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim, float neg_log_period) {
   int half = dim / 2;
@@ -376,6 +425,36 @@ int mi_mse_fwd_bwd(const void* pred, const float* target, void* dpred, float* lo
   (void)grad_scale;
   hipLaunchKernelGGL(k_mse, dim3(grid_for(total, 1024)), dim3(kThreads), 0, st, (const bf16*)pred, target, (bf16*)dpred, loss, C, V, total,
                      1.0f / (float)(total * C));
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_l1_fwd_bwd(const void* pred, const float* target, void* dpred, float* loss, int N, int C, int64_t V, int accumulate, hipStream_t st) {
+  int64_t total = (int64_t)N * V;
+  if (total <= 0) return MI_ERR_BAD_ARG;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(k_l1, dim3(grid_for(total, 1024)), dim3(kThreads), 0, st, (const bf16*)pred, target, (bf16*)dpred, loss, C, V, total,
+                     1.0f / (float)(total * C));
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_reparam_kl_fwd(const void* mu, const void* sigma, const float* eps, void* z, float* loss, int N, int C, int64_t V, float kl_weight,
+                      hipStream_t st) {
+  int64_t total = (int64_t)N * V;
+  if (total <= 0 || C <= 0) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_reparam_kl_fwd, dim3(grid_for(total, 1024)), dim3(kThreads), 0, st, (const bf16*)mu, (const bf16*)sigma, eps, (bf16*)z, loss,
+                     C, V, total, kl_weight / (float)N);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_reparam_kl_bwd(const void* mu, const void* sigma, const float* eps, const void* dz, void* dmu, void* dsigma, int N, int C, int64_t V,
+                      float kl_weight, hipStream_t st) {
+  int64_t total = (int64_t)N * V;
+  if (total <= 0 || C <= 0) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_reparam_kl_bwd, dim3(grid_for(total, 1024)), dim3(kThreads), 0, st, (const bf16*)mu, (const bf16*)sigma, eps,
+                     (const bf16*)dz, (bf16*)dmu, (bf16*)dsigma, C, V, total, kl_weight / (float)N);
   MI_CHECK_LAUNCH();
   return 0;
 }

@@ -7,6 +7,9 @@ No torch autograd and no torch compute kernels in the step: the tape engine driv
 optimizer is one fused launch over the flat parameter arena, and the whole step can be captured in a hipGraph
 (`capture=True`) and replayed, which removes the Python / launch overhead of ~600 kernel launches.
 
+`AETrainer` is the same thing for the generator step of train_autoencoder.AutoEncoder.train_one_epoch (T-AE:406-435)
+without its third-party perceptual/adversarial terms: encode -> sample -> decode -> L1 + kl_weight * KL -> backward -> Adam.
+
 Data parallelism: one process per GPU; the trainable prefix of the flat gradient arena is all-reduced
 (average) over RCCL in a few large buckets -- statically unused `proj_attn.*` tensors live outside that prefix.
 """
@@ -17,6 +20,7 @@ import torch.distributed as dist
 
 from . import ddp
 from . import engine as E
+from . import hipops as ops
 from ._lib import call, ptr
 
 F32 = torch.float32
@@ -41,9 +45,10 @@ class DDPMSchedule:
         self.sqrt_1macp = (1.0 - acp).sqrt().to(device)
 
 
-class DDPMTrainer:
-    def __init__(self, model, lr=2e-5, optimizer="AdamW", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
-                 schedule: DDPMSchedule | None = None, process_group=None, bucket_mb=64, device=None):
+class _ArenaTrainer:
+    """Optimizer state over the flat arena, gradient averaging and hipGraph capture; subclasses give forward_backward()."""
+
+    def __init__(self, model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device):
         self.model = model
         self.device = torch.device(device or "cuda")
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -52,7 +57,6 @@ class DDPMTrainer:
             raise ValueError("optimizer must be 'Adam' or 'AdamW'")
         self.weight_decay = (0.01 if self.decoupled else 0.0) if weight_decay is None else weight_decay  # torch defaults
         self.max_grad_norm = max_grad_norm
-        self.schedule = schedule or DDPMSchedule(device=self.device)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         self.bucket_elems = bucket_mb * (1 << 20) // 4
@@ -69,6 +73,68 @@ class DDPMTrainer:
         self._static = None
 
     # ------------------------------------------------------------------ pieces
+    def all_reduce_grads(self):
+        if self.world > 1:
+            ddp.average_gradients(self.arena.grad, self.arena.n_trainable, self.pg, self.bucket_elems)
+
+    def optimizer_step(self):
+        a = self.arena
+        n = a.n_trainable
+        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
+        if clip:
+            call("mi_sumsq_f32", ptr(a.grad), n, ptr(self.sumsq), 0)
+        call("mi_adam_step", ptr(a.data), ptr(a.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n, self.lr, self.betas[0], self.betas[1],
+             self.eps, self.weight_decay, int(self.decoupled), ptr(self.sumsq) if clip else None, float(self.max_grad_norm or 0.0),
+             ptr(self.step_count))
+
+    # ------------------------------------------------------------------ one step
+    def step(self, *inputs):
+        """Eager step; returns the (device) loss tensor without synchronising."""
+        self.forward_backward(*inputs)
+        self.all_reduce_grads()
+        self.optimizer_step()
+        return self.loss
+
+    def capture(self, *inputs, warmup=2):
+        """Capture forward+backward and the optimizer as hipGraphs around static input buffers (the all-reduce stays
+        eager between them so RCCL is never inside a capture).  Call step_graph() afterwards."""
+        self._static = tuple(t.clone() for t in inputs)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):  # creates conv plans / workspaces (hipMalloc) outside capture
+                self.forward_backward(*self._static)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        # thread_local: a collective library's watchdog thread polling events must not invalidate the capture
+        self._g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
+            self.forward_backward(*self._static)
+        self._g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_opt, capture_error_mode="thread_local"):
+            self.optimizer_step()
+        self._graph = True
+
+    def step_graph(self, *inputs):
+        """Replay; inputs given (positionally, None = keep) are copied into the static buffers first."""
+        assert self._graph, "call capture() first"
+        for buf, t in zip(self._static, inputs):
+            if t is not None:
+                buf.copy_(t)
+        self._g_fb.replay()
+        self.all_reduce_grads()
+        self._g_opt.replay()
+        return self.loss
+
+
+class DDPMTrainer(_ArenaTrainer):
+    """step(x0, noise, timesteps): x0/noise fp32 NCDHW, timesteps int64 [N]."""
+
+    def __init__(self, model, lr=2e-5, optimizer="AdamW", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
+                 schedule: DDPMSchedule | None = None, process_group=None, bucket_mb=64, device=None):
+        super().__init__(model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device)
+        self.schedule = schedule or DDPMSchedule(device=self.device)
+
     def forward_backward(self, x0, noise, timesteps):
         """q-sample -> UNet -> MSE -> backward into the gradient arena.  x0/noise: fp32 NCDHW, timesteps: int64 [N]."""
         m = self.model
@@ -90,57 +156,44 @@ class DDPMTrainer:
         ctx.tape.backward(pred, dpred)
         ctx.tape.grads.clear(), ctx.tape.keep.clear()
 
-    def all_reduce_grads(self):
-        if self.world > 1:
-            ddp.average_gradients(self.arena.grad, self.arena.n_trainable, self.pg, self.bucket_elems)
 
-    def optimizer_step(self):
-        a = self.arena
-        n = a.n_trainable
-        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
-        if clip:
-            call("mi_sumsq_f32", ptr(a.grad), n, ptr(self.sumsq), 0)
-        call("mi_adam_step", ptr(a.data), ptr(a.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n, self.lr, self.betas[0], self.betas[1],
-             self.eps, self.weight_decay, int(self.decoupled), ptr(self.sumsq) if clip else None, float(self.max_grad_norm or 0.0),
-             ptr(self.step_count))
+class AETrainer(_ArenaTrainer):
+    """step(images, eps): images fp32 NCDHW, eps fp32 latent-shaped NCDHW (the torch.randn_like of AEKL:786-787 made an
+    input so that a captured graph sees fresh noise and tests can pin it).  Defaults are the reference's generator
+    optimizer (Adam, lr 5e-5, grad_clip_max_norm 1; T-AE:428-434, 470) and 3-D kl_weight (CFG:995-1026)."""
 
-    # ------------------------------------------------------------------ one step
-    def step(self, x0, noise, timesteps):
-        """Eager step; returns the (device) loss tensor without synchronising."""
-        self.forward_backward(x0, noise, timesteps)
-        self.all_reduce_grads()
-        self.optimizer_step()
-        return self.loss
+    def __init__(self, model, lr=5e-5, optimizer="Adam", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
+                 kl_weight=1e-7, process_group=None, bucket_mb=64, device=None):
+        super().__init__(model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device)
+        self.kl_weight = float(kl_weight)
 
-    def capture(self, x0, noise, timesteps, warmup=2):
-        """Capture forward+backward and the optimizer as hipGraphs around static input buffers (the all-reduce stays
-        eager between them so RCCL is never inside a capture).  Call step_graph() afterwards."""
-        self._static = (x0.clone(), noise.clone(), timesteps.clone())
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(warmup):  # creates conv plans / workspaces (hipMalloc) outside capture
-                self.forward_backward(*self._static)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        # thread_local: a collective library's watchdog thread polling events must not invalidate the capture
-        self._g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
-            self.forward_backward(*self._static)
-        self._g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_opt, capture_error_mode="thread_local"):
-            self.optimizer_step()
-        self._graph = True
+    def forward_backward(self, images, eps):
+        m, a = self.model, self.arena
+        a.grad.zero_()
+        self.loss.zero_()
+        n, c = images.shape[0], images.shape[1]
+        sp = tuple(images.shape[2:])
+        v = 1
+        for s in sp:
+            v *= s
+        x_cl = ops.to_channels_last(images)
+        ctx = E.Ctx(a, m._plans, grad_enabled=True, prepacked=m.pack_all())
+        tape = ctx.tape
+        mu, sigma = m._encode_run(ctx, x_cl, need_dx=False)
+        lc = mu.shape[-1]
+        lv = mu.numel() // (n * lc)
+        z = torch.empty_like(mu)
+        call("mi_reparam_kl_fwd", ptr(mu), ptr(sigma), ptr(eps), ptr(z), ptr(self.loss), n, lc, lv, self.kl_weight)
 
-    def step_graph(self, x0=None, noise=None, timesteps=None):
-        assert self._graph, "call capture() first"
-        if x0 is not None:
-            self._static[0].copy_(x0)
-        if noise is not None:
-            self._static[1].copy_(noise)
-        if timesteps is not None:
-            self._static[2].copy_(timesteps)
-        self._g_fb.replay()
-        self.all_reduce_grads()
-        self._g_opt.replay()
-        return self.loss
+        def bwd():
+            dz = tape.take(z)
+            dmu, dsigma = torch.empty_like(mu), torch.empty_like(sigma)
+            call("mi_reparam_kl_bwd", ptr(mu), ptr(sigma), ptr(eps), ptr(dz), ptr(dmu), ptr(dsigma), n, lc, lv, self.kl_weight)
+            tape.put(mu, dmu), tape.put(sigma, dsigma)
+
+        tape.record(bwd)
+        recon = m._decode_run(ctx, z, True)
+        drecon = torch.empty_like(recon)
+        call("mi_l1_fwd_bwd", ptr(recon), ptr(images), ptr(drecon), ptr(self.loss), n, recon.shape[-1], v, 1)
+        tape.backward(recon, drecon)
+        tape.grads.clear(), tape.keep.clear()

@@ -86,6 +86,46 @@ def _gemm_labelled(a, lda, sa1, sa2, b, ldb, sb1, sb2, c, ldc, sc1, sc2, m, n, k
 
 engine._gemm = _gemm_labelled
 
+if len(sys.argv) > 3 and sys.argv[3] == "c3a":  # AutoencoderKL config of BASELINE configs[2] through the autograd edge
+    from medical_image_generation_amd.autoencoderkl import AutoencoderKL
+    down = [[[1] * 3, [3] * 3, [1] * 3], [[2] * 3, [3] * 3, [1] * 3], [[2] * 3, [3] * 3, [1] * 3]]
+    kw = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=8, num_res_blocks=2, num_channels=[32, 64, 128],
+              attention_levels=[False] * 3, norm_num_groups=16, with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False,
+              downsample_parameters=down, upsample_parameters=list(reversed(down))[:-1])
+    torch.manual_seed(0)
+    ae = AutoencoderKL(**kw).to(dev)
+    opt = torch.optim.Adam(ae.parameters(), lr=5e-5)
+    xa = torch.rand((2, 1, size, size, size), device=dev)
+
+    def ae_step():
+        opt.zero_grad(set_to_none=True)
+        rec, mu, sg = ae(xa)
+        loss = torch.nn.functional.l1_loss(rec, xa) + 1e-7 * 0.5 * torch.sum(mu.pow(2) + sg.pow(2) - torch.log(sg.pow(2)) - 1) / xa.shape[0]
+        loss.backward()
+        opt.step()
+
+    for _ in range(2):
+        ae_step()
+    torch.cuda.synchronize()
+    enabled[0] = True
+    import time
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ae_step()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    enabled[0] = False
+    tot = collections.defaultdict(lambda: [0, 0.0])
+    for name, lab, e0, e1 in records:
+        k = (name, lab or "")
+        tot[k][0] += 1
+        tot[k][1] += e0.elapsed_time(e1)
+    rows = sorted(tot.items(), key=lambda kv: -kv[1][1])
+    print(f"wall {wall:.2f} ms/step; bracketed HIP calls {sum(v[1] for v in tot.values()) / steps:.2f} ms/step")
+    for (name, lab), (cnt, ms) in rows[:45]:
+        print(f"{name:28s} {lab:28s} x{cnt // steps:3d}  {ms / steps:8.3f} ms/step  {ms / cnt * 1e3:9.1f} us/call")
+    sys.exit(0)
+
 torch.manual_seed(42)
 net = DiffusionModelUNet(**bench.C4)
 for n, p in net.named_parameters():
