@@ -115,12 +115,16 @@ int mi_softmax_bwd(const void* probs, const float* dprobs, void* dscores, int64_
 
 /* ---- fused self-attention (no S x S matrix in HBM) for head dims 32 / 64: AttentionBlock._attention, UNet:406-416 ------------
  * qkv: [B*S][ld] bf16 rows holding Q | K | V (C columns each, head h at column h*d);  y = softmax(QK^T*scale)V (+ resid);
- * lse: [B*heads][S] fp32 (log2 domain) saved for the backward;  mi_attn_bwd writes dQ | dK | dV into dqkv (layout of qkv) */
+ * lse: [B*heads][S] fp32 (log2 domain) saved for the backward;  mi_attn_bwd writes dQ | dK | dV into dqkv (layout of qkv).
+ * ws: scratch of mi_attn_workspace_bytes() bytes: with it the reduction axis (keys; queries for dK/dV) is split over several
+ * workgroups whose partial results a merge kernel combines -- a batch-1 16^3 level has only 128 query blocks for 256 CUs.
+ * ws == NULL (or too small) runs the single-pass kernels. */
 int mi_attn_supported(int C, int heads);
-int mi_attn_fwd(const void* qkv, int ld, int C, int heads, int B, int S, float scale, const void* resid, void* y, float* lse,
-                hipStream_t stream);
+int64_t mi_attn_workspace_bytes(int C, int heads, int B, int S);
+int mi_attn_fwd(const void* qkv, int ld, int C, int heads, int B, int S, float scale, const void* resid, void* y, float* lse, void* ws,
+                int64_t ws_bytes, hipStream_t stream);
 int mi_attn_bwd(const void* qkv, int ld, int C, int heads, int B, int S, float scale, const void* y, const void* resid, const void* dy,
-                const float* lse, float* dsum, void* dqkv, hipStream_t stream);
+                const float* lse, float* dsum, void* dqkv, void* ws, int64_t ws_bytes, hipStream_t stream);
 
 /* ---- get_timestep_embedding (UNet:461-485), nn.SiLU on the embedding vector (UNet:1833, 692) --------------------------- */
 int mi_timestep_embedding(const int64_t* timesteps, float* out, int B, int dim, float max_period, hipStream_t stream);

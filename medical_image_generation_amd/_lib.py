@@ -53,8 +53,9 @@ _SIGS = {
     "mi_softmax_fwd": [_p, _p, _l, _i, _p],
     "mi_softmax_bwd": [_p, _p, _p, _l, _i, _f, _p],
     "mi_attn_supported": [_i, _i],
-    "mi_attn_fwd": [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p],
-    "mi_attn_bwd": [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p],
+    "mi_attn_workspace_bytes": [_i, _i, _i, _i],
+    "mi_attn_fwd": [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _l, _p],
+    "mi_attn_bwd": [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _p, _p, _p, _l, _p],
     "mi_timestep_embedding": [_p, _p, _i, _i, _f, _p],
     "mi_silu_f32": [_p, _p, _l, _p],
     "mi_silu_bwd_f32": [_p, _p, _p, _l, _p],
@@ -69,8 +70,8 @@ _SIGS = {
     "mi_clip_grad_by_norm": [_p, _l, _p, _f, _p],
     "mi_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _p, _p],
 }
-_RET = {"mi_gn_workspace_bytes": _l}
-_NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes", "mi_attn_supported"}
+_RET = {"mi_gn_workspace_bytes": _l, "mi_attn_workspace_bytes": _l}
+_NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes", "mi_attn_supported", "mi_attn_workspace_bytes"}
 
 _lib = None
 

@@ -19,6 +19,9 @@
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
+constexpr f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+// v_exp_f32 without exp2f()'s denormal-range scaling: arguments here are <= 0 and results below 2^-126 may flush to zero
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct AttnArgs {
   const bf16* qkv;   // [B*S][ld]
@@ -32,6 +35,11 @@ struct AttnArgs {
   const bf16* o;      // [B*S][C] forward output WITHOUT residual is not stored; o = y - x is recomputed from y and resid
   float* dsum;        // [B*heads][S]  D = rowsum(dO * O)
   bf16* dqkv;         // [B*S][ld]
+  // split over the reduction axis (keys in forward / dQ, queries in dK,dV): blockIdx.z handles `tps` 64-row tiles and writes
+  // a partial result; k_attn_merge_* combine them.  nsplit == 1: results go straight to y / dqkv.
+  int nsplit, tps;
+  bf16* part;         // forward: [nsplit][B*S][C] normalised partial outputs; backward: [nsplit][B*S][3C] partial dQ | dK | dV
+  float* part_ml;     // forward: [nsplit][B*heads][S][2] running max (log2 domain) and sum of each partial
 };
 
 // 16 bytes = 8 bf16 of row `row` at element offset `col` (ld in elements); zero when row >= limit
@@ -70,15 +78,20 @@ struct Tiles {  // LDS images of a 64-row tile of two operands
   static constexpr int PIECES = 64 * D / 8 / 256;   // 16-byte pieces per thread per operand
 };
 
-// stage a 64-row tile [rows r0.., D cols at column offset col] into LDS with pitch P
+// 64 rows r0.. of an S-row operand (base = row 0, first column of the head) into registers; rows >= S read as zeros through the
+// buffer range check, and the per-tile part of the address lives in the (scalar) descriptor: no vector address math in the loops
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const bf16* base, int r0, int S, int ld) {
+  const int rem = S - r0;
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(base + (int64_t)r0 * ld), 0, rem > 0 ? rem * ld * 2 : 0, 0x00020000);
+}
 template <int D>
-__device__ __forceinline__ void tile_load(u32x4 (&reg)[Tiles<D>::PIECES], const bf16* base, int64_t row_base, int r0, int limit, int ld,
-                                          int col) {
+__device__ __forceinline__ void tile_load(u32x4 (&reg)[Tiles<D>::PIECES], const bf16* base, int r0, int S, int ld) {
+  const __amdgpu_buffer_rsrc_t rs = tile_rsrc(base, r0, S, ld);
 #pragma unroll
   for (int i = 0; i < Tiles<D>::PIECES; ++i) {
     int pc = threadIdx.x + 256 * i;
     int r = pc / (D / 8), c = (pc % (D / 8)) * 8;
-    reg[i] = ld16(base, row_base + r0 + r, row_base + limit, ld, col + c);
+    reg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (r * ld + c) * 2, 0, 0));
   }
 }
 template <int D>
@@ -117,55 +130,61 @@ __global__ void __launch_bounds__(256) k_attn_fwd(AttnArgs a) {
     for (int e = 0; e < 16; ++e) o[i][e] = 0.f;
   float m = -INFINITY, l = 0.f;
 
+  const int kbeg = blockIdx.z * a.tps * 64, kend = min(S, kbeg + a.tps * 64);
+  const bf16 *kbase = a.qkv + rb * a.ld + kc, *vbase = a.qkv + rb * a.ld + vc;
   u32x4 kr[T::PIECES], vr[T::PIECES];
-  tile_load<D>(kr, a.qkv, rb, 0, S, a.ld, kc);
-  tile_load<D>(vr, a.qkv, rb, 0, S, a.ld, vc);
-  for (int k0 = 0; k0 < S; k0 += 64) {
+  tile_load<D>(kr, kbase, kbeg, S, a.ld);
+  tile_load<D>(vr, vbase, kbeg, S, a.ld);
+  for (int k0 = kbeg; k0 < kend; k0 += 64) {
     __syncthreads();
     tile_store<D>(kr, kt, T::PA);
     tile_store<D>(vr, vt, T::PB);
     __syncthreads();
-    if (k0 + 64 < S) {
-      tile_load<D>(kr, a.qkv, rb, k0 + 64, S, a.ld, kc);
-      tile_load<D>(vr, a.qkv, rb, k0 + 64, S, a.ld, vc);
+    if (k0 + 64 < kend) {
+      tile_load<D>(kr, kbase, k0 + 64, S, a.ld);
+      tile_load<D>(vr, vbase, k0 + 64, S, a.ld);
     }
     // S^T tile: 64 keys (2 blocks of 32) x 32 queries
     f32x16 st[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, T::PA, kb * 32, 0, lane), qf[0], kZero16, 0, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) st[kb][e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < DK; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, T::PA, kb * 32, ks, lane), qf[ks], st[kb], 0, 0, 0);
+      for (int ks = 1; ks < DK; ++ks) st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, T::PA, kb * 32, ks, lane), qf[ks], st[kb], 0, 0, 0);
     }
-    float tmax = -INFINITY;
+    if (k0 + 64 > S) {  // ragged last tile: keys >= S must not count (their K rows were read as zeros)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if (k0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= S) st[kb][e] = -INFINITY;
+    }
+    float tmax = st[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = k0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        float t = key < S ? st[kb][e] * c : -INFINITY;
-        st[kb][e] = t;
-        tmax = fmaxf(tmax, t);
-      }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));  // the two lane halves hold the other keys of the same query
-    const float mn = fmaxf(m, tmax);
-    const float alpha = mn == -INFINITY ? 1.f : exp2f(m - mn);
+      for (int e = 0; e < 16; ++e) tmax = fmaxf(tmax, st[kb][e]);
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c;  // the two lane halves hold the other keys of the same query (c > 0)
+    if (__builtin_amdgcn_ballot_w64(tmax > m)) {  // some query's running max moved: rescale (rare once the maxima settle)
+      const float mn = fmaxf(m, tmax);
+      const float alpha = ex2(m - mn);  // first tile: m = -inf -> 0
+      l *= alpha;
+      m = mn;
+#pragma unroll
+      for (int i = 0; i < DVB; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    }
     float ps = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        float p = mn == -INFINITY ? 0.f : exp2f(st[kb][e] - mn);
+        const float p = ex2(st[kb][e] * c - m);
         st[kb][e] = p;
         ps += p;
       }
-    l = l * alpha + ps;
-    m = mn;
-#pragma unroll
-    for (int i = 0; i < DVB; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[i][e] *= alpha;
+    l += ps;
     // O^T += V^T P^T : per 16-key step the probability registers are the B operand, V^T comes from the transposed read
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -178,6 +197,21 @@ __global__ void __launch_bounds__(256) k_attn_fwd(AttnArgs a) {
   }
   const float lt = l + __shfl_xor(l, 32, 64);
   const float inv = lt > 0.f ? 1.f / lt : 0.f;
+  if (a.nsplit > 1) {
+    if (q < S) {
+      if (h == 0) *(float2*)(a.part_ml + (((int64_t)blockIdx.z * gridDim.y + bh) * S + q) * 2) = make_float2(m, lt);
+      bf16* po = a.part + ((int64_t)blockIdx.z * gridDim.y / a.heads * S + rb + q) * a.C;
+#pragma unroll
+      for (int i = 0; i < DVB; ++i)
+#pragma unroll
+        for (int grp = 0; grp < 4; ++grp) {
+          const int col = hd * D + i * 32 + grp * 8 + h * 4;
+          u32x2 w = {pack2(o[i][grp * 4] * inv, o[i][grp * 4 + 1] * inv), pack2(o[i][grp * 4 + 2] * inv, o[i][grp * 4 + 3] * inv)};
+          *(u32x2*)(po + col) = w;
+        }
+    }
+    return;
+  }
   if (q < S) {
     if (h == 0 && a.lse) a.lse[(int64_t)bh * S + q] = m + log2f(lt);
 #pragma unroll
@@ -249,34 +283,32 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dq[i][e] = 0.f;
 
+  const int kbeg = blockIdx.z * a.tps * 64, kend = min(S, kbeg + a.tps * 64);
+  const bf16 *kbase = a.qkv + rb * a.ld + kc, *vbase = a.qkv + rb * a.ld + vc;
   u32x4 kr[T::PIECES], vr[T::PIECES];
-  tile_load<D>(kr, a.qkv, rb, 0, S, a.ld, kc);
-  tile_load<D>(vr, a.qkv, rb, 0, S, a.ld, vc);
-  for (int k0 = 0; k0 < S; k0 += 64) {
+  tile_load<D>(kr, kbase, kbeg, S, a.ld);
+  tile_load<D>(vr, vbase, kbeg, S, a.ld);
+  for (int k0 = kbeg; k0 < kend; k0 += 64) {
     __syncthreads();
     tile_store<D>(kr, kt, T::PB);
     tile_store<D>(vr, vt, T::PA);
     __syncthreads();
-    if (k0 + 64 < S) {
-      tile_load<D>(kr, a.qkv, rb, k0 + 64, S, a.ld, kc);
-      tile_load<D>(vr, a.qkv, rb, k0 + 64, S, a.ld, vc);
+    if (k0 + 64 < kend) {
+      tile_load<D>(kr, kbase, k0 + 64, S, a.ld);
+      tile_load<D>(vr, vbase, k0 + 64, S, a.ld);
     }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      f32x16 st, dp;
+      f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, T::PB, kb * 32, 0, lane), qf[0], kZero16, 0, 0, 0);   // S^T  = K Q^T
+      f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vt, T::PA, kb * 32, 0, lane), dof[0], kZero16, 0, 0, 0);  // dP^T = V dO^T
 #pragma unroll
-      for (int e = 0; e < 16; ++e) st[e] = dp[e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < DK; ++ks) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, T::PB, kb * 32, ks, lane), qf[ks], st, 0, 0, 0);   // S^T  = K Q^T
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vt, T::PA, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);  // dP^T = V dO^T
+      for (int ks = 1; ks < DK; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(kt, T::PB, kb * 32, ks, lane), qf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vt, T::PA, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);
       }
+      // keys >= S need no mask: their K rows are zeros, so whatever dS^T holds there multiplies zeros in dQ^T += K^T dS^T
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int key = k0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float p = key < S ? exp2f(st[e] * c - lse) : 0.f;
-        st[e] = p * (dp[e] - dq_row) * a.scale;  // dS^T
-      }
+      for (int e = 0; e < 16; ++e) st[e] = ex2(st[e] * c - lse) * (dp[e] - dq_row) * a.scale;  // dS^T = P (dP - D) scale
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const bf16x8 df = pack_acc8(st, s);
@@ -285,6 +317,9 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq(AttnArgs a) {
       }
     }
   }
+  bf16* out = a.dqkv;
+  int ldo = a.ld;
+  if (a.nsplit > 1) out = a.part + (int64_t)blockIdx.z * (gridDim.y / a.heads) * S * 3 * a.C, ldo = 3 * a.C;
   if (q < S) {
 #pragma unroll
     for (int i = 0; i < DB; ++i)
@@ -292,7 +327,7 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dq(AttnArgs a) {
       for (int grp = 0; grp < 4; ++grp) {
         const int col = qc + i * 32 + grp * 8 + h * 4;
         u32x2 w = {pack2(dq[i][grp * 4], dq[i][grp * 4 + 1]), pack2(dq[i][grp * 4 + 2], dq[i][grp * 4 + 3])};
-        *(u32x2*)(a.dqkv + (rb + q) * a.ld + col) = w;
+        *(u32x2*)(out + (rb + q) * ldo + col) = w;
       }
   }
 }
@@ -327,10 +362,12 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) dk[i][e] = dv[i][e] = 0.f;
 
+  const int qbeg = blockIdx.z * a.tps * 64, qend = min(S, qbeg + a.tps * 64);
+  const bf16 *qbase = a.qkv + rb * a.ld + qc, *dbase = a.dy + rb * a.C + hd * D;
   u32x4 qr[T::PIECES], dr[T::PIECES];
-  tile_load<D>(qr, a.qkv, rb, 0, S, a.ld, qc);
-  tile_load<D>(dr, a.dy, rb, 0, S, a.C, hd * D);
-  for (int q0 = 0; q0 < S; q0 += 64) {
+  tile_load<D>(qr, qbase, qbeg, S, a.ld);
+  tile_load<D>(dr, dbase, qbeg, S, a.C);
+  for (int q0 = qbeg; q0 < qend; q0 += 64) {
     __syncthreads();
     tile_store<D>(qr, qt, T::PB);
     tile_store<D>(dr, dt, T::PB);
@@ -340,25 +377,25 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv(AttnArgs a) {
       dsum_s[threadIdx.x] = qq < S ? a.dsum[(int64_t)bh * S + qq] : 0.f;
     }
     __syncthreads();
-    if (q0 + 64 < S) {
-      tile_load<D>(qr, a.qkv, rb, q0 + 64, S, a.ld, qc);
-      tile_load<D>(dr, a.dy, rb, q0 + 64, S, a.C, hd * D);
+    if (q0 + 64 < qend) {
+      tile_load<D>(qr, qbase, q0 + 64, S, a.ld);
+      tile_load<D>(dr, dbase, q0 + 64, S, a.C);
     }
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
-      f32x16 st, dp;
+      f32x16 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qt, T::PB, qb * 32, 0, lane), kf[0], kZero16, 0, 0, 0);  // S  = Q K^T
+      f32x16 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dt, T::PB, qb * 32, 0, lane), vf[0], kZero16, 0, 0, 0);  // dP = dO V^T
 #pragma unroll
-      for (int e = 0; e < 16; ++e) st[e] = dp[e] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < DK; ++ks) {
-        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qt, T::PB, qb * 32, ks, lane), kf[ks], st, 0, 0, 0);  // S  = Q K^T
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dt, T::PB, qb * 32, ks, lane), vf[ks], dp, 0, 0, 0);  // dP = dO V^T
+      for (int ks = 1; ks < DK; ++ks) {
+        st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qt, T::PB, qb * 32, ks, lane), kf[ks], st, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dt, T::PB, qb * 32, ks, lane), vf[ks], dp, 0, 0, 0);
       }
+      // keys >= S (lanes past the end) compute garbage-free finite values that are never stored: no key mask needed
       f32x16 pr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int ql = qb * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        const float p = key < S ? exp2f(st[e] * c - lse_s[ql]) : 0.f;
+        const float p = ex2(st[e] * c - lse_s[ql]);
         pr[e] = p;
         st[e] = p * (dp[e] - dsum_s[ql]) * a.scale;  // dS
       }
@@ -373,6 +410,9 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv(AttnArgs a) {
       }
     }
   }
+  bf16* out = a.dqkv;
+  int ldo = a.ld;
+  if (a.nsplit > 1) out = a.part + (int64_t)blockIdx.z * (gridDim.y / a.heads) * S * 3 * a.C, ldo = 3 * a.C;
   if (key < S) {
 #pragma unroll
     for (int i = 0; i < DB; ++i)
@@ -381,11 +421,82 @@ __global__ void __launch_bounds__(256) k_attn_bwd_dkv(AttnArgs a) {
         const int off = i * 32 + grp * 8 + h * 4;
         u32x2 wk = {pack2(dk[i][grp * 4], dk[i][grp * 4 + 1]), pack2(dk[i][grp * 4 + 2], dk[i][grp * 4 + 3])};
         u32x2 wv = {pack2(dv[i][grp * 4], dv[i][grp * 4 + 1]), pack2(dv[i][grp * 4 + 2], dv[i][grp * 4 + 3])};
-        *(u32x2*)(a.dqkv + (rb + key) * a.ld + kc + off) = wk;
-        *(u32x2*)(a.dqkv + (rb + key) * a.ld + vc + off) = wv;
+        *(u32x2*)(out + (rb + key) * ldo + kc + off) = wk;
+        *(u32x2*)(out + (rb + key) * ldo + vc + off) = wv;
       }
   }
 }
+
+// ------------------------------------------------------------------------------------------------ merging the splits
+// forward: y = sum_i w_i O_i / sum_i w_i (+ resid), w_i = l_i 2^(m_i - M);  lse = M + log2(sum_i w_i).  One thread per 8 columns.
+__global__ void __launch_bounds__(256) k_attn_merge_fwd(const bf16* __restrict__ part, const float* __restrict__ ml, const bf16* __restrict__ resid,
+                                                        bf16* __restrict__ y, float* __restrict__ lse, int C, int heads, int S, int64_t rows,
+                                                        int nsplit) {
+  const int c8 = C / 8, D = C / heads;
+  const int64_t idx = blockIdx.x * 256ll + threadIdx.x;
+  if (idx >= rows * c8) return;
+  const int64_t row = idx / c8;
+  const int col = (int)(idx - row * c8) * 8, hd = col / D;
+  const int64_t b = row / S, q = row - b * S, BH = rows / S * heads;
+  float mi[8], li[8], M = -INFINITY;
+  for (int z = 0; z < nsplit; ++z) {
+    const float2 v = *(const float2*)(ml + ((z * BH + b * heads + hd) * S + q) * 2);
+    mi[z] = v.x, li[z] = v.y;
+    M = fmaxf(M, v.x);
+  }
+  float L = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < nsplit; ++z) {
+    const float w = mi[z] == -INFINITY ? 0.f : li[z] * exp2f(mi[z] - M);
+    L += w;
+    const F8 p = unpack8(*(const u32x4*)(part + (z * rows + row) * C + col));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += w * p.v[j];
+  }
+  const float inv = L > 0.f ? 1.f / L : 0.f;
+  u32x4 rr = {0u, 0u, 0u, 0u};
+  if (resid) rr = *(const u32x4*)(resid + row * C + col);
+  const F8 r = unpack8(rr);
+  F8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o.v[j] = acc[j] * inv + r.v[j];
+  *(u32x4*)(y + row * C + col) = pack8(o);
+  if (lse && col == hd * D) lse[(b * heads + hd) * S + q] = M + log2f(L);
+}
+// backward: dqkv[row][0..3C) = sum over splits of the partial gradients
+__global__ void __launch_bounds__(256) k_attn_merge_bwd(const bf16* __restrict__ part, bf16* __restrict__ dqkv, int ld, int C3, int64_t rows,
+                                                        int nsplit) {
+  const int c8 = C3 / 8;
+  const int64_t idx = blockIdx.x * 256ll + threadIdx.x;
+  if (idx >= rows * c8) return;
+  const int64_t row = idx / c8;
+  const int col = (int)(idx - row * c8) * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < nsplit; ++z) {
+    const F8 p = unpack8(*(const u32x4*)(part + (z * rows + row) * C3 + col));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += p.v[j];
+  }
+  F8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o.v[j] = acc[j];
+  *(u32x4*)(dqkv + row * ld + col) = pack8(o);
+}
+
+constexpr int kMaxSplit = 8;
+// enough workgroups for ~2 per CU (8 waves; measured best at S = 4096), at least 4 tiles (256 rows of the reduction axis) per split
+void pick_split(int B, int heads, int S, int& nsplit, int& tps) {
+  const int base = (S + 127) / 128 * B * heads, ntiles = (S + 63) / 64;
+  int want = 512 / (base > 0 ? base : 1);
+  static const int env = [] { const char* e = getenv("MI_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+  if (env > 0) want = env;
+  want = want < 1 ? 1 : (want > kMaxSplit ? kMaxSplit : want);
+  if (!env && want > ntiles / 4) want = ntiles / 4 > 0 ? ntiles / 4 : 1;
+  tps = (ntiles + want - 1) / want;
+  nsplit = (ntiles + tps - 1) / tps;
+}
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t fwd_ws(int C, int heads, int B, int S, int ns) { return ns > 1 ? align256((size_t)ns * B * S * C * 2) + (size_t)ns * B * heads * S * 8 : 0; }
+size_t bwd_ws(int C, int B, int S, int ns) { return ns > 1 ? (size_t)ns * B * S * 3 * C * 2 : 0; }
 
 bool bad(int C, int heads, int S, int B, int ld) {
   if (heads <= 0 || C % heads) return true;
@@ -399,15 +510,32 @@ extern "C" {
 
 int mi_attn_supported(int C, int heads) { return heads > 0 && C % heads == 0 && (C / heads == 32 || C / heads == 64); }
 
-int mi_attn_fwd(const void* qkv, int ld, int C, int heads, int B, int S, float scale, const void* resid, void* y, float* lse,
-                hipStream_t st) {
+int64_t mi_attn_workspace_bytes(int C, int heads, int B, int S) {
+  if (bad(C, heads, S, B, 3 * C)) return 0;
+  int ns, tps;
+  pick_split(B, heads, S, ns, tps);
+  const size_t f = fwd_ws(C, heads, B, S, ns), b = bwd_ws(C, B, S, ns);
+  return (int64_t)(f > b ? f : b);
+}
+
+int mi_attn_fwd(const void* qkv, int ld, int C, int heads, int B, int S, float scale, const void* resid, void* y, float* lse, void* ws,
+                int64_t ws_bytes, hipStream_t st) {
   if (bad(C, heads, S, B, ld) || !qkv || !y) return MI_ERR_BAD_ARG;
   AttnArgs a{};
   a.qkv = (const bf16*)qkv; a.ld = ld; a.C = C; a.heads = heads; a.S = S; a.scale = scale;
   a.resid = (const bf16*)resid; a.y = (bf16*)y; a.lse = lse;
-  dim3 grid((S + 127) / 128, B * heads), blk(256);
+  pick_split(B, heads, S, a.nsplit, a.tps);
+  if (!ws || (size_t)ws_bytes < fwd_ws(C, heads, B, S, a.nsplit)) a.nsplit = 1, a.tps = (S + 63) / 64;  // no scratch: one pass over all keys
+  a.part = (bf16*)ws;
+  a.part_ml = (float*)((char*)ws + align256((size_t)a.nsplit * B * S * C * 2));
+  dim3 grid((S + 127) / 128, B * heads, a.nsplit), blk(256);
   if (C / heads == 64) hipLaunchKernelGGL(k_attn_fwd<64>, grid, blk, 0, st, a);
   else hipLaunchKernelGGL(k_attn_fwd<32>, grid, blk, 0, st, a);
+  if (a.nsplit > 1) {
+    const int64_t rows = (int64_t)B * S, n = rows * (C / 8);
+    hipLaunchKernelGGL(k_attn_merge_fwd, dim3((unsigned)((n + 255) / 256)), blk, 0, st, a.part, a.part_ml, a.resid, a.y, lse, C, heads, S, rows,
+                       a.nsplit);
+  }
   MI_CHECK_LAUNCH();
   return 0;
 }
@@ -415,21 +543,28 @@ int mi_attn_fwd(const void* qkv, int ld, int C, int heads, int B, int S, float s
 // dy: gradient w.r.t. the attention output (same tensor as the gradient of y); y, resid: forward output and its residual input
 // (O = y - resid is what the row term needs); dqkv receives dQ | dK | dV in the layout of qkv.  dsum: [B*heads][S] scratch.
 int mi_attn_bwd(const void* qkv, int ld, int C, int heads, int B, int S, float scale, const void* y, const void* resid, const void* dy,
-                const float* lse, float* dsum, void* dqkv, hipStream_t st) {
+                const float* lse, float* dsum, void* dqkv, void* ws, int64_t ws_bytes, hipStream_t st) {
   if (bad(C, heads, S, B, ld) || !qkv || !y || !dy || !lse || !dsum || !dqkv) return MI_ERR_BAD_ARG;
   AttnArgs a{};
   a.qkv = (const bf16*)qkv; a.ld = ld; a.C = C; a.heads = heads; a.S = S; a.scale = scale;
   a.dy = (const bf16*)dy; a.lse = const_cast<float*>(lse); a.dsum = dsum; a.dqkv = (bf16*)dqkv;
+  pick_split(B, heads, S, a.nsplit, a.tps);
+  if (!ws || (size_t)ws_bytes < bwd_ws(C, B, S, a.nsplit)) a.nsplit = 1, a.tps = (S + 63) / 64;
+  a.part = (bf16*)ws;
   const int64_t rows = (int64_t)B * S;
   hipLaunchKernelGGL(k_attn_dsum, dim3((int)((rows + 3) / 4)), dim3(256), 0, st, (const bf16*)dy, (const bf16*)y, (const bf16*)resid, dsum, C,
                      heads, S, rows);
-  dim3 grid((S + 127) / 128, B * heads), blk(256);
+  dim3 grid((S + 127) / 128, B * heads, a.nsplit), blk(256);
   if (C / heads == 64) {
     hipLaunchKernelGGL(k_attn_bwd_dq<64>, grid, blk, 0, st, a);
     hipLaunchKernelGGL(k_attn_bwd_dkv<64>, grid, blk, 0, st, a);
   } else {
     hipLaunchKernelGGL(k_attn_bwd_dq<32>, grid, blk, 0, st, a);
     hipLaunchKernelGGL(k_attn_bwd_dkv<32>, grid, blk, 0, st, a);
+  }
+  if (a.nsplit > 1) {
+    const int64_t n = rows * (3 * C / 8);
+    hipLaunchKernelGGL(k_attn_merge_bwd, dim3((unsigned)((n + 255) / 256)), blk, 0, st, a.part, a.dqkv, ld, 3 * C, rows, a.nsplit);
   }
   MI_CHECK_LAUNCH();
   return 0;

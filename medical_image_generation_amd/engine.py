@@ -298,7 +298,10 @@ def _attention_flash(ctx, x, name, st, xn, wqkv, qkv, b, s, c, heads, scale):
     d_, h_, w_ = x.shape[1:4]
     y = torch.empty_like(x)
     lse = torch.empty((b * heads, s), dtype=F32, device=dev)
-    call("mi_attn_fwd", ptr(qkv), 3 * c, c, heads, b, s, float(scale), ptr(x), ptr(y), ptr(lse))
+    nws = _lib.call_raw("mi_attn_workspace_bytes", c, heads, b, s)
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)  # partial results of the split kernels; dead after each call
+    call("mi_attn_fwd", ptr(qkv), 3 * c, c, heads, b, s, float(scale), ptr(x), ptr(y), ptr(lse), ptr(ws), nws)
+    del ws
     ctx.count(2 * b * s * c * 3 * c)
     ctx.count(4 * b * s * s * c)
     if ctx.tape is not None:
@@ -310,7 +313,9 @@ def _attention_flash(ctx, x, name, st, xn, wqkv, qkv, b, s, c, heads, scale):
                 return
             dqkv = torch.empty((b * s, 3 * c), dtype=BF16, device=dev)
             dsum = torch.empty((b * heads, s), dtype=F32, device=dev)
-            call("mi_attn_bwd", ptr(qkv), 3 * c, c, heads, b, s, float(scale), ptr(y), ptr(x), ptr(dy), ptr(lse), ptr(dsum), ptr(dqkv))
+            ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+            call("mi_attn_bwd", ptr(qkv), 3 * c, c, heads, b, s, float(scale), ptr(y), ptr(x), ptr(dy), ptr(lse), ptr(dsum), ptr(dqkv),
+                 ptr(ws), nws)
             _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy, b, s, c)
 
         tape.record(bwd)

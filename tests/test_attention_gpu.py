@@ -10,8 +10,11 @@ dev = torch.device("cuda")
 
 
 @pytest.mark.parametrize("B,H,S,d", [(1, 1, 64, 32), (2, 2, 64, 32), (1, 4, 512, 64), (2, 1, 1000, 64), (1, 2, 4096, 64), (1, 3, 200, 32)])
-def test_flash_attention_fwd_bwd(B, H, S, d):
-    from medical_image_generation_amd._lib import call, ptr
+@pytest.mark.parametrize("split", [True, False])
+def test_flash_attention_fwd_bwd(B, H, S, d, split):
+    """split: hand the kernels their scratch, so the reduction axis is cut into up to 8 partial passes + a merge kernel
+    (2 / 4 / 8 ways for the S = 512 / 1000 / 4096 cases); without it the single-pass kernels run."""
+    from medical_image_generation_amd._lib import call, call_raw, ptr
     C = H * d
     g = torch.Generator().manual_seed(S + d)
     qkv = (torch.randn(B, S, 3 * C, generator=g) * 1.5).bfloat16()
@@ -29,14 +32,18 @@ def test_flash_attention_fwd_bwd(B, H, S, d):
     qd, xd, dyd = qkv.to(dev).reshape(B * S, 3 * C), x.to(dev), dy.to(dev)
     y = torch.empty_like(xd)
     lse = torch.empty(B * H, S, device=dev)
-    call("mi_attn_fwd", ptr(qd), 3 * C, C, H, B, S, scale, ptr(xd), ptr(y), ptr(lse))
+    nws = call_raw("mi_attn_workspace_bytes", C, H, B, S) if split else 0
+    assert nws > 0 or not split or S < 512
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+    call("mi_attn_fwd", ptr(qd), 3 * C, C, H, B, S, scale, ptr(xd), ptr(y), ptr(lse), ptr(ws) if split else None, nws)
     err = float((y.float().cpu() - y_ref.detach()).abs().max())
     assert err <= 2e-2 * float(y_ref.abs().max()), f"fwd err {err}"
     lse_ref = torch.logsumexp((q @ k.transpose(-1, -2) * scale).detach(), dim=-1).reshape(B * H, S) / math.log(2)
     assert float((lse.cpu() - lse_ref).abs().max()) <= 2e-2
     dqkv = torch.zeros_like(qd)
     dsum = torch.empty(B * H, S, device=dev)
-    call("mi_attn_bwd", ptr(qd), 3 * C, C, H, B, S, scale, ptr(y), ptr(xd), ptr(dyd), ptr(lse), ptr(dsum), ptr(dqkv))
+    call("mi_attn_bwd", ptr(qd), 3 * C, C, H, B, S, scale, ptr(y), ptr(xd), ptr(dyd), ptr(lse), ptr(dsum), ptr(dqkv),
+         ptr(ws) if split else None, nws)
     ref = qr.grad.reshape(B * S, 3 * C)
     got = dqkv.float().cpu()
     for name, sl in (("dQ", slice(0, C)), ("dK", slice(C, 2 * C)), ("dV", slice(2 * C, 3 * C))):
