@@ -51,10 +51,13 @@ __device__ __forceinline__ u32x4 pack8(const F8& f) {
   return r;
 }
 
-__device__ __forceinline__ float silu_f(float u) { return u / (1.0f + __expf(-u)); }
+// sigmoid through v_exp_f32 / v_rcp_f32 (1 ulp each): an IEEE divide costs ~10 VALU instructions and a branch per element, which
+// made the streaming GroupNorm kernels VALU-bound; exp2(+large) = inf -> rcp = 0 and exp2(-large) = 0 -> rcp(1) = 1 are the right limits
+__device__ __forceinline__ float sigmoid_f(float u) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * u)); }
+__device__ __forceinline__ float silu_f(float u) { return u * sigmoid_f(u); }
 // d/du [u * sigmoid(u)] = s * (1 + u * (1 - s))
 __device__ __forceinline__ float silu_grad_f(float u) {
-  float s = 1.0f / (1.0f + __expf(-u));
+  float s = sigmoid_f(u);
   return s * (1.0f + u * (1.0f - s));
 }
 

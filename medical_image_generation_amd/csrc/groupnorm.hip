@@ -150,37 +150,44 @@ __global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ p
   }
 }
 
-// y = act(x * scale + shift).  The host sizes the grid so that the grid stride is a multiple of C8: a thread then keeps ONE channel
-// octet for its whole loop and its 16 scale / shift values stay in registers (reloaded only when the image index changes) --
-// per 16-byte piece the kernel issues 2 vector-memory instructions instead of 18.
+// y = act(x * scale + shift).  grid = (gx, N) with gx * kT a multiple of C8: a thread keeps ONE channel octet of ONE image for its
+// whole loop, so its 16 scale / shift values stay in registers, the loop has no integer division, and 4 independent 16-byte loads
+// are in flight per lane.
+template <bool SILU>
 __global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int xcs, const float* __restrict__ scale_shift,
-                                                 bf16* __restrict__ y, int ycs, int C8, int64_t V, int silu, int64_t total) {
+                                                 bf16* __restrict__ y, int ycs, int C8, int64_t V) {
   const int C = C8 * 8;
-  const int64_t i0 = blockIdx.x * (int64_t)kT + threadIdx.x;
-  const int cg = (int)(i0 % C8);
-  int64_t n_cur = -1;
+  const int tid = blockIdx.x * kT + threadIdx.x;
+  const int cg = tid % C8, R = gridDim.x * kT / C8;
+  const int64_t n = blockIdx.y;
   float sc[8], sh[8];
-  for (int64_t i = i0; i < total; i += (int64_t)gridDim.x * kT) {
-    const int64_t nv = i / C8;
-    const int64_t n = nv / V;
-    if (n != n_cur) {
-      load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
-      n_cur = n;
-    }
-    F8 f = unpack8(*(const u32x4*)(x + nv * xcs + cg * 8));
+  load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
+  const bf16* xb = x + n * V * xcs + cg * 8;
+  bf16* yb = y + n * V * ycs + cg * 8;
+  for (int64_t v = tid / C8; v < V; v += 4 * (int64_t)R) {
+    u32x4 raw[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float u = f.v[j] * sc[j] + sh[j];
-      f.v[j] = silu ? silu_f(u) : u;
+    for (int k = 0; k < 4; ++k)
+      if (v + k * (int64_t)R < V) raw[k] = *(const u32x4*)(xb + (v + k * (int64_t)R) * xcs);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (v + k * (int64_t)R >= V) break;
+      F8 f = unpack8(raw[k]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float u = f.v[j] * sc[j] + sh[j];
+        f.v[j] = SILU ? silu_f(u) : u;
+      }
+      *(u32x4*)(yb + (v + k * (int64_t)R) * ycs) = pack8(f);
     }
-    *(u32x4*)(y + nv * ycs + cg * 8) = pack8(f);
   }
 }
 
 // backward partials: (sum du, sum du*x) per (n, chunk, c);  du = g * silu'(x*scale+shift)  (or g when !silu)
+template <bool SILU>
 __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                        const float* __restrict__ scale_shift, float* __restrict__ partial, int C,
-                                                       int64_t V, int64_t vchunk, int silu) {
+                                                       int64_t V, int64_t vchunk) {
   extern __shared__ float sm[];
   const int C8 = C / 8, rows = kT / C8;
   const int cg = threadIdx.x % C8, r = threadIdx.x / C8;
@@ -208,7 +215,7 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float du = fg.v[j];
-          if (silu) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
+          if (SILU) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
           s1[j] += du;
           s2[j] += du * fx.v[j];
         }
@@ -262,48 +269,65 @@ __global__ void __launch_bounds__(256) k_gn_bwd_finalize(const float* __restrict
   }
 }
 
-// dx = a*du + b*x + c (+ add); grid stride a multiple of C8 as in k_gn_apply: 40 per-channel constants stay in registers
+// dx = a*du + b*x + c (+ add); grid as in k_gn_apply: 40 per-channel constants stay in registers
+template <bool SILU>
 __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                      const float* __restrict__ scale_shift, const float* __restrict__ coef,
                                                      const bf16* __restrict__ add, int acs, bf16* __restrict__ dx, int dcs, int C8,
-                                                     int64_t V, int silu, int64_t total) {
+                                                     int64_t V) {
   const int C = C8 * 8;
-  const int64_t i0 = blockIdx.x * (int64_t)kT + threadIdx.x;
-  const int cg = (int)(i0 % C8);
-  int64_t n_cur = -1;
+  const int tid = blockIdx.x * kT + threadIdx.x;
+  const int cg = tid % C8, R = gridDim.x * kT / C8;
+  const int64_t n = blockIdx.y;
   float sc[8], sh[8], ca[8], cb[8], cc[8];
-  for (int64_t i = i0; i < total; i += (int64_t)gridDim.x * kT) {
-    const int64_t nv = i / C8;
-    const int64_t n = nv / V;
-    if (n != n_cur) {
-      load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
-      const float* cf = coef + (n * C + cg * 8) * 3;
+  load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
+  {
+    const float* cf = coef + (n * C + cg * 8) * 3;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { ca[j] = cf[3 * j]; cb[j] = cf[3 * j + 1]; cc[j] = cf[3 * j + 2]; }
-      n_cur = n;
-    }
-    F8 fx = unpack8(*(const u32x4*)(x + nv * xcs + cg * 8));
-    F8 fg = unpack8(*(const u32x4*)(g + nv * gcs + cg * 8));
-    F8 o;
+    for (int j = 0; j < 8; ++j) { ca[j] = cf[3 * j]; cb[j] = cf[3 * j + 1]; cc[j] = cf[3 * j + 2]; }
+  }
+  const bf16* xb = x + n * V * xcs + cg * 8;
+  const bf16* gb = g + n * V * gcs + cg * 8;
+  const bf16* ab = add ? add + n * V * acs + cg * 8 : nullptr;
+  bf16* db = dx + n * V * dcs + cg * 8;
+  for (int64_t v = tid / C8; v < V; v += 2 * (int64_t)R) {
+    u32x4 rx[2], rg[2], ra[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float du = fg.v[j];
-      if (silu) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
-      o.v[j] = ca[j] * du + cb[j] * fx.v[j] + cc[j];
+    for (int k = 0; k < 2; ++k) {
+      const int64_t vk = v + k * (int64_t)R;
+      if (vk < V) {
+        rx[k] = *(const u32x4*)(xb + vk * xcs);
+        rg[k] = *(const u32x4*)(gb + vk * gcs);
+        if (ab) ra[k] = *(const u32x4*)(ab + vk * acs);
+      }
     }
-    if (add) {
-      F8 fa = unpack8(*(const u32x4*)(add + nv * acs + cg * 8));
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o.v[j] += fa.v[j];
+    for (int k = 0; k < 2; ++k) {
+      const int64_t vk = v + k * (int64_t)R;
+      if (vk >= V) break;
+      F8 fx = unpack8(rx[k]), fg = unpack8(rg[k]), o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float du = fg.v[j];
+        if (SILU) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
+        o.v[j] = ca[j] * du + cb[j] * fx.v[j] + cc[j];
+      }
+      if (ab) {
+        F8 fa = unpack8(ra[k]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] += fa.v[j];
+      }
+      *(u32x4*)(db + vk * dcs) = pack8(o);
     }
-    *(u32x4*)(dx + nv * dcs + cg * 8) = pack8(o);
   }
 }
 
-// grid for the streaming apply kernels: <= cap blocks, total thread count a multiple of C8 (see k_gn_apply)
-inline int64_t apply_grid(int64_t total, int C8) {
+// x-extent of the (gx, N) grid of the streaming apply kernels: ~4096 blocks in all, gx * kT a multiple of C8 (see k_gn_apply);
+// total = 16-byte pieces of ONE image
+inline int64_t apply_grid(int64_t total, int C8, int N) {
   int64_t grid = (total + kT - 1) / kT;
-  if (grid > 256 * 16) grid = 256 * 16;
+  const int64_t cap = 256 * 16 / N > 64 ? 256 * 16 / N : 64;
+  if (grid > cap) grid = cap;
   int m = C8;  // kT * grid % C8 == 0  <=>  grid % (C8 / gcd(C8, kT)) == 0
   for (int a = kT, b = C8; b;) { int t = a % b; a = b; b = t; m = C8 / a; }
   if (grid >= m) grid -= grid % m;
@@ -346,10 +370,9 @@ int mi_gn_stats(const void* x, int x_cstride, int N, int64_t V, int C, int G, fl
 int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y, int y_cstride, int N, int64_t V, int C, int silu,
                 hipStream_t st) {
   if (C <= 0 || (C & 7) || (x_cstride & 7) || (y_cstride & 7) || N <= 0 || V <= 0) return MI_ERR_BAD_ARG;
-  int64_t total = (int64_t)N * V * (C / 8);
-  int64_t grid = apply_grid(total, C / 8);
-  hipLaunchKernelGGL(k_gn_apply, dim3((int)grid), dim3(kT), 0, st, (const bf16*)x, x_cstride, scale_shift, (bf16*)y, y_cstride, C / 8, V,
-                     silu, total);
+  int64_t grid = apply_grid(V * (C / 8), C / 8, N);
+  auto k = silu ? k_gn_apply<true> : k_gn_apply<false>;
+  hipLaunchKernelGGL(k, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)x, x_cstride, scale_shift, (bf16*)y, y_cstride, C / 8, V);
   MI_CHECK_LAUNCH();
   return 0;
 }
@@ -363,14 +386,15 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   int64_t vc = pick_vchunk(V);
   int chunks = (int)((V + vc - 1) / vc);
   int rows = kT / (C / 8);
-  hipLaunchKernelGGL(k_gn_bwd_partial, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride,
-                     (const bf16*)x, x_cstride, scale_shift, (float*)workspace, C, V, vc, silu);
+  auto kp = silu ? k_gn_bwd_partial<true> : k_gn_bwd_partial<false>;
+  hipLaunchKernelGGL(kp, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride, (const bf16*)x,
+                     x_cstride, scale_shift, (float*)workspace, C, V, vc);
   hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(N * G), dim3(256), sizeof(float) * 2 * (size_t)(C / G), st, (const float*)workspace, chunks, C,
                      G, V, gamma, mean_rstd, coef, dgamma, dbeta);
-  int64_t total = (int64_t)N * V * (C / 8);
-  int64_t grid = apply_grid(total, C / 8);
-  hipLaunchKernelGGL(k_gn_bwd_apply, dim3((int)grid), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift,
-                     coef, (const bf16*)add, add_cstride, (bf16*)dx, dx_cstride, C / 8, V, silu, total);
+  int64_t grid = apply_grid(V * (C / 8), C / 8, N);
+  auto ka = silu ? k_gn_bwd_apply<true> : k_gn_bwd_apply<false>;
+  hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift, coef,
+                     (const bf16*)add, add_cstride, (bf16*)dx, dx_cstride, C / 8, V);
   MI_CHECK_LAUNCH();
   return 0;
 }
