@@ -1086,7 +1086,10 @@ __device__ __forceinline__ void pack_one(const float* __restrict__ w, u32x4* __r
 }
 __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ w, u32x4* __restrict__ out,
                                                       const int* __restrict__ items, int nfrags, u32x4* __restrict__ out2,
-                                                      const int* __restrict__ items2, int nfrags2, int Co_t, int Ci_t, int KT) {
+                                                      const int* __restrict__ items2, int nfrags2, int Co_t, int Ci_t, int KT,
+                                                      float* __restrict__ c1w, int c1n) {
+  if (c1w && blockIdx.x == 0)  // single-channel convs (conv_c1.hip) use the fp32 weights as they are
+    for (int i = threadIdx.x; i < c1n; i += 256) c1w[i] = w[i];
   pack_one(w, out, items, nfrags, out2, items2, nfrags2, Co_t, Ci_t, KT, blockIdx.x * 256 + threadIdx.x);
 }
 // every conv of a network in ONE launch (the per-conv launches are mostly launch floor: 67 convs, ~10 us each)
@@ -1094,6 +1097,7 @@ struct PackDesc {
   const float* w; u32x4* out; const int* items; u32x4* out2; const int* items2;
   int nfrags, nfrags2, Co_t, Ci_t, KT;
   int block0;  // first block of this conv
+  float* c1w; int c1n;  // fp32 copy for the single-channel kernels (null: none)
 };
 __global__ void __launch_bounds__(256) k_pack_batch(const PackDesc* __restrict__ descs, int n) {
   int lo = 0, hi = n - 1;  // last descriptor with block0 <= blockIdx.x
@@ -1102,6 +1106,8 @@ __global__ void __launch_bounds__(256) k_pack_batch(const PackDesc* __restrict__
     if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const PackDesc d = descs[lo];
+  if (d.c1w && (int)blockIdx.x == d.block0)
+    for (int i = threadIdx.x; i < d.c1n; i += 256) d.c1w[i] = d.w[i];
   pack_one(d.w, d.out, d.items, d.nfrags, d.out2, d.items2, d.nfrags2, d.Co_t, d.Ci_t, d.KT, ((int)blockIdx.x - d.block0) * 256 + threadIdx.x);
 }
 
@@ -1225,6 +1231,10 @@ struct mi_conv_plan {
   bf16* d_dxs = nullptr;  // depth image of dx
   bool strided = false;
   bool full27 = false;  // k3 s1 p1 on all three axes: compile-time tap nest
+  // conv_c1.hip: one channel on one side (network input / output conv).  Those kernels read fp32 weights [C][27]: the pack
+  // kernels copy the master weight into d_c1w
+  bool c1_in = false, c1_out = false, c1_packed = false;
+  float* d_c1w = nullptr;
   bool v27_fwd = false, v27_dg = false;  // forward / data gradient run on conv27.hip (LDS-DMA kernel); weights packed with perm16
   bool v11_fwd = false, v11_dg = false;  // 1x1x1: forward / data gradient run on conv1x1.hip (streaming GEMM); weights packed with perm16
 };
@@ -1422,6 +1432,16 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   // forward: loader reads x (or its depth image: dims Dp.., Q*Cin channels); outputs on the (Do,Ho,Wo) grid
   P->g_fwd = make_geom(2, P->Do, P->Ho, P->Wo, halo_f, N);
   static const int use27 = env_int("MI_CONV27", 1);  // 0: keep every conv on the table-driven kernel (A/B runs)
+  {
+    static const int use_c1 = env_int("MI_CONV_C1", 1);
+    auto c_ok = [](int c) { return c >= 8 && c <= 64 && (c & 7) == 0; };
+    P->c1_in = use_c1 && P->full27 && Cin == 1 && c_ok(Cout);
+    P->c1_out = use_c1 && P->full27 && Cout == 1 && c_ok(Cin);
+    if (P->c1_in || P->c1_out) {
+      const int C = P->c1_in ? Cout : Cin;
+      if (hipMalloc((void**)&P->d_c1w, (size_t)27 * C * 4) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
+    }
+  }
   const bool geo27 = P->full27 && P->g_fwd.TD == 4 && P->g_fwd.TH == 8 && P->g_fwd.TW == 8;
   P->v27_fwd = use27 && geo27 && (Cin % 8) == 0;
   P->v27_dg = use27 && geo27 && (Cout % 8) == 0;
@@ -1481,6 +1501,7 @@ int mi_conv_plan_destroy(mi_conv_plan* P) {
   if (P->d_uitems) (void)hipFree(P->d_uitems);
   if (P->d_part) (void)hipFree(P->d_part);
   if (P->d_cspart) (void)hipFree(P->d_cspart);
+  if (P->d_c1w) (void)hipFree(P->d_c1w);
   if (P->d_xs) (void)hipFree(P->d_xs);
   if (P->d_dxs) (void)hipFree(P->d_dxs);
   delete P;
@@ -1497,7 +1518,9 @@ int mi_conv_plan_out_dims(const mi_conv_plan* P, int* dims3) {
 int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
   if (!P || !w) return MI_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_pack_weights, dim3(((P->fwd.nfrags + P->dg.nfrags) * 64 + 255) / 256), dim3(256), 0, st, w, P->fwd.d_wpk,
-                     P->fwd.d_items, P->fwd.nfrags, P->dg.d_wpk, P->dg.d_items, P->dg.nfrags, P->Cout, P->Cin, P->KT);
+                     P->fwd.d_items, P->fwd.nfrags, P->dg.d_wpk, P->dg.d_items, P->dg.nfrags, P->Cout, P->Cin, P->KT, P->d_c1w,
+                     P->d_c1w ? 27 * P->Cin * P->Cout : 0);
+  P->c1_packed = true;
   MI_CHECK_LAUNCH();
   return 0;
 }
@@ -1511,12 +1534,14 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
   std::vector<PackDesc> h((size_t)n);
   int blocks = 0;
   for (int i = 0; i < n; ++i) {
-    const mi_conv_plan* P = plans[i];
+    mi_conv_plan* P = plans[i];
     if (!P || !weights[i]) return MI_ERR_BAD_ARG;
+    P->c1_packed = true;
     PackDesc& d = h[(size_t)i];
     d.w = weights[i]; d.out = P->fwd.d_wpk; d.items = P->fwd.d_items; d.out2 = P->dg.d_wpk; d.items2 = P->dg.d_items;
     d.nfrags = P->fwd.nfrags; d.nfrags2 = P->dg.nfrags; d.Co_t = P->Cout; d.Ci_t = P->Cin; d.KT = P->KT;
     d.block0 = blocks;
+    d.c1w = P->d_c1w; d.c1n = P->d_c1w ? 27 * P->Cin * P->Cout : 0;
     blocks += ((P->fwd.nfrags + P->dg.nfrags) * 64 + 255) / 256;
   }
   mi_pack_batch* B = new mi_pack_batch();
@@ -1543,6 +1568,11 @@ int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
 int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const float* addvec, int addvec_stride,
                 const void* res, int res_cs, void* y, int y_cs, hipStream_t st) {
   if (!P || !x || !y || x_cs < P->Cin || y_cs < P->Cout) return MI_ERR_BAD_ARG;
+  if ((P->c1_in || P->c1_out) && P->c1_packed && !scale_shift && !res) {
+    int e = P->c1_in ? mi_launch_c1_expand(x, x_cs, P->d_c1w, addvec, addvec_stride, y, y_cs, P->N, P->Di, P->Hi, P->Wi, P->Cout, 0, st)
+                     : mi_launch_c1_reduce(x, x_cs, P->d_c1w, addvec, addvec_stride, y, y_cs, P->N, P->Di, P->Hi, P->Wi, P->Cin, st);
+    if (e != MI_ERR_UNSUPPORTED) return e;
+  }
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   const bf16* src = (const bf16*)x;
@@ -1589,6 +1619,10 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
 
 int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_cs, hipStream_t st) {
   if (!P || !dy || !dx || dy_cs < P->Cout || dx_cs < P->Cin) return MI_ERR_BAD_ARG;
+  if (P->c1_out && P->c1_packed) {  // dx[v][ci] = sum_t dy[v - t] W[0][ci][t]: the 1 -> C kernel with the taps flipped
+    int e = mi_launch_c1_expand(dy, dy_cs, P->d_c1w, nullptr, 0, dx, dx_cs, P->N, P->Di, P->Hi, P->Wi, P->Cin, 1, st);
+    if (e != MI_ERR_UNSUPPORTED) return e;
+  }
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   a.x = (const bf16*)dy; a.x_cs = dy_cs; a.N = P->N; a.Di = P->Do; a.Hi = P->Ho; a.Wi = P->Wo; a.Cin = P->Cout;

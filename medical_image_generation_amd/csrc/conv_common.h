@@ -73,3 +73,8 @@ int mi_launch_conv27(const ConvArgs& a, int NCB, int flip, int ntiles, int ny, h
 int mi_launch_conv1x1(const ConvArgs& a, int NCB, int ny, hipStream_t st);
 int mi_launch_wgrad1x1(const void* x, int x_cs, int Cin, const void* dy, int dy_cs, int Cout, int N, int64_t V, float* dw, float* colsum,
                        int colsum_stride, hipStream_t st);
+// conv_c1.hip: k3 s1 p1 3-D convs with one channel on one side (fp32 master weights [C][27] read directly)
+int mi_launch_c1_expand(const void* s, int s_cs, const float* w, const float* addvec, int av_stride, void* y, int y_cs, int N, int D, int H,
+                        int W, int C, int flip, hipStream_t st);
+int mi_launch_c1_reduce(const void* x, int x_cs, const float* w, const float* addvec, int av_stride, void* y, int y_cs, int N, int D, int H,
+                        int W, int C, hipStream_t st);

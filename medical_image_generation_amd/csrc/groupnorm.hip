@@ -30,7 +30,9 @@ __device__ __forceinline__ void load_ss(const float* ss, int c0, float* sc, floa
 // Block tail: 16 per-thread partials (8 channels x 2 moments) -> out[c][2].  Lanes that own the same 8 channels sit C8
 // apart in a wave, so when C8 is a power of two the voxel lanes are folded with xor-shuffles (log2(64/C8) steps) and LDS only
 // sees one row per wave; otherwise every row goes through LDS.
-__device__ __forceinline__ void block_fold(float (&a)[8], float (&b)[8], float* sm, float* out, int C, int C8, int rows, int r, int cg) {
+// out: this image's [C][chunks][2] slab -- chunk-fastest, so the finish kernels read each channel's partials as one contiguous run
+__device__ __forceinline__ void block_fold(float (&a)[8], float (&b)[8], float* sm, float* out, int chunks, int chunk, int C, int C8, int rows,
+                                           int r, int cg) {
   const bool pow2 = (C8 & (C8 - 1)) == 0 && C8 <= 64;
   if (pow2) {
     for (int m = C8; m < 64; m <<= 1) {
@@ -49,7 +51,8 @@ __device__ __forceinline__ void block_fold(float (&a)[8], float (&b)[8], float* 
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += kT) out[i] = (sm[i] + sm[2 * C + i]) + (sm[4 * C + i] + sm[6 * C + i]);
+    for (int i = threadIdx.x; i < 2 * C; i += kT)
+      out[((int64_t)(i >> 1) * chunks + chunk) * 2 + (i & 1)] = (sm[i] + sm[2 * C + i]) + (sm[4 * C + i] + sm[6 * C + i]);
   } else {
     if (r < rows) {
 #pragma unroll
@@ -62,12 +65,12 @@ __device__ __forceinline__ void block_fold(float (&a)[8], float (&b)[8], float* 
     for (int i = threadIdx.x; i < 2 * C; i += kT) {
       float acc = 0.f;
       for (int k = 0; k < rows; ++k) acc += sm[k * C * 2 + i];
-      out[i] = acc;
+      out[((int64_t)(i >> 1) * chunks + chunk) * 2 + (i & 1)] = acc;
     }
   }
 }
 
-// partial[n][chunk][c][2] = (sum x, sum x^2) over the chunk's voxels
+// partial[n][c][chunk][2] = (sum x, sum x^2) over the chunk's voxels
 __global__ void __launch_bounds__(kT) k_gn_partial(const bf16* __restrict__ x, int cstride, float* __restrict__ partial, int C,
                                                    int64_t V, int64_t vchunk) {
   extern __shared__ float sm[];  // [rows][C][2]
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(kT) k_gn_partial(const bf16* __restrict__ x, i
       }
     }
   }
-  block_fold(s, q, sm, partial + ((int64_t)n * gridDim.x + blockIdx.x) * C * 2, C, C8, rows, r, cg);
+  block_fold(s, q, sm, partial + (int64_t)n * gridDim.x * C * 2, gridDim.x, blockIdx.x, C, C8, rows, r, cg);
 }
 
 // one block (256 threads) per (n, g): up to 1024 chunk partials per channel, so the loads are spread over 4 waves
@@ -126,11 +129,13 @@ __global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ p
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   double s = 0.0, q = 0.0;
-  for (int i = threadIdx.x; i < chunks * cpg; i += 256) {
-    int ch = i / cpg, c = g * cpg + i % cpg;
-    const float* p = partial + (((int64_t)n * chunks + ch) * C + c) * 2;
-    s += (double)p[0];
-    q += (double)p[1];
+  {  // the group's channels are adjacent, so its chunks * cpg (sum, sumsq) pairs are ONE contiguous run
+    const float2* p = (const float2*)(partial + ((int64_t)n * C + g * cpg) * chunks * 2);
+    for (int i = threadIdx.x; i < chunks * cpg; i += 256) {
+      const float2 v = p[i];
+      s += (double)v.x;
+      q += (double)v.y;
+    }
   }
   block_sum2_d(s, q, red);
   const double m = (double)V * cpg;
@@ -222,7 +227,7 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ 
       }
     }
   }
-  block_fold(s1, s2, sm, partial + ((int64_t)n * gridDim.x + blockIdx.x) * C * 2, C, C8, rows, r, cg);
+  block_fold(s1, s2, sm, partial + (int64_t)n * gridDim.x * C * 2, gridDim.x, blockIdx.x, C, C8, rows, r, cg);
 }
 
 // per (n, g): coefficients of dx = a*du + b*x + c per channel, and the affine-parameter gradients
@@ -238,10 +243,11 @@ __global__ void __launch_bounds__(256) k_gn_bwd_finalize(const float* __restrict
   for (int i = 0; i < cpg; ++i) {  // channels of the group in turn; the 256 threads split the chunks
     int c = g * cpg + i;
     double s1 = 0.0, s2 = 0.0;
+    const float2* p = (const float2*)(partial + ((int64_t)n * C + c) * chunks * 2);
     for (int ch = threadIdx.x; ch < chunks; ch += 256) {
-      const float* p = partial + (((int64_t)n * chunks + ch) * C + c) * 2;
-      s1 += (double)p[0];
-      s2 += (double)p[1];
+      const float2 v = p[ch];
+      s1 += (double)v.x;
+      s2 += (double)v.y;
     }
     block_sum2_d(s1, s2, red);
     double s2hat = (double)rstd * (s2 - (double)mean * s1);  // sum du * xhat

@@ -140,6 +140,9 @@ CONV_CASES = [
     (1, 96, 32, (4, 8, 16), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 1, 32, (8, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 32, 1, (8, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (2, 1, 16, (5, 9, 11), (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # single-channel streaming kernels (conv_c1.hip), ragged tiles, 2 images
+    (2, 24, 1, (6, 7, 10), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    (1, 64, 1, (4, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (2, 8, 8, (4, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (1, 96, 64, (4, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (2, 64, 32, (8, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # streaming 1x1 kernels: per-image dy column sums, 2 images
@@ -177,8 +180,10 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     check(dw.cpu() - 1, wr.grad, 1e-2, "conv wgrad")
     check(cs.cpu() - 1, g.sum(dim=(2, 3, 4)), 1e-2, "fused dy column sums (bias / temb gradient)")
     cb = torch.ones(cout, device=dev)  # 1-D target: summed over the batch as well (= the bias gradient)
-    plan.wgrad(xc, gc, torch.zeros_like(w).to(dev), colsum=cb)
+    dw2 = torch.ones_like(w).to(dev)
+    plan.wgrad(xc, gc, dw2, colsum=cb)
     check(cb.cpu() - 1, g.sum(dim=(0, 2, 3, 4)), 1e-2, "fused bias gradient")
+    check(dw2.cpu() - 1, wr.grad, 1e-2, "conv wgrad (batch-summed bias gradient variant)")
 
 
 def test_conv_fused_prologue_epilogue(ops):
