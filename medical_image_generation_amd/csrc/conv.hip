@@ -1145,10 +1145,58 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
     }
   }
 }
+// Few slabs, wide layers (256 -> 256: 1.8 M weights, 4 slabs): the element-per-thread kernel above spends its time in the scattered
+// read-modify-write of dw (one 4-byte element per 108-byte stride).  Here a block owns ONE output row of a (cout, cin) pair with all
+// its taps: the slab sums go through LDS and land in dw as one contiguous run of 32 * KT floats.
+__global__ void __launch_bounds__(256) k_wgrad_reduce_rows(const float* __restrict__ part, int64_t split_stride, int nsplit,
+                                                           const int* __restrict__ uitems, const int* __restrict__ pair_off, int npairs,
+                                                           float* __restrict__ dw, int Co_t, int Ci_t, int KT) {
+  __shared__ float sm[32][33];   // [ci_l][tap]  (KT <= 32)
+  __shared__ unsigned present;   // taps this pair owns (strided convs split the taps over several pairs)
+  const int pair = blockIdx.x >> 5, co_l = blockIdx.x & 31;
+  const int off = pair_off[pair];
+  const int nt = (int)(((pair + 1 < npairs ? (int64_t)pair_off[pair + 1] : split_stride) - off) >> 10);
+  const int* it0 = uitems + (off >> 10) * 4;
+  const int co = it0[1] + co_l, ci0 = it0[2];
+  if (co >= Co_t) return;  // whole block
+  if (threadIdx.x == 0) present = 0u;
+  __syncthreads();
+  const int ci_l = threadIdx.x & 31;
+  for (int t = threadIdx.x >> 5; t < nt; t += 8) {
+    const int tap = it0[t * 4];
+    if (tap < 0) continue;
+    const float* p = part + off + t * 1024 + co_l * 32 + ci_l;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 3 < nsplit; k += 4) {
+      s0 += p[(int64_t)k * split_stride];
+      s1 += p[(int64_t)(k + 1) * split_stride];
+      s2 += p[(int64_t)(k + 2) * split_stride];
+      s3 += p[(int64_t)(k + 3) * split_stride];
+    }
+    for (; k < nsplit; ++k) s0 += p[(int64_t)k * split_stride];
+    sm[ci_l][tap] = (s0 + s1) + (s2 + s3);
+    if (ci_l == 0) atomicOr(&present, 1u << tap);
+  }
+  __syncthreads();
+  const unsigned mask = present;
+  const int nci = Ci_t - ci0 < 32 ? Ci_t - ci0 : 32;
+  float* row = dw + ((int64_t)co * Ci_t + ci0) * KT;
+  for (int e = threadIdx.x; e < nci * KT; e += 256) {
+    const int c = e / KT, tap = e - c * KT;
+    if (mask >> tap & 1u) row[e] += sm[c][tap];
+  }
+}
+
+int env_int(const char* name, int dflt);
 inline void launch_wgrad_reduce(const float* part, int64_t split_stride, int nsplit, const int* uitems, int nitems, float* dw, int Co_t, int Ci_t,
-                                int KT, hipStream_t st) {
+                                int KT, const int* pair_off, int npairs, hipStream_t st) {
+  static const int rows_kernel = env_int("MI_WGRAD_REDUCE_ROWS", 1);
   if (nsplit >= 32)
     hipLaunchKernelGGL(k_wgrad_reduce<8>, dim3(nitems * 32), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT);
+  else if (rows_kernel && KT <= 32 && npairs >= 8)
+    hipLaunchKernelGGL(k_wgrad_reduce_rows, dim3(npairs * 32), dim3(256), 0, st, part, split_stride, nsplit, uitems, pair_off, npairs, dw, Co_t,
+                       Ci_t, KT);
   else if (nsplit >= 8)
     hipLaunchKernelGGL(k_wgrad_reduce<4>, dim3(nitems * 16), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT);
   else
@@ -1751,7 +1799,8 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
       }
       if (geo3) hipLaunchKernelGGL(k_conv_wgrad2<true>, grid, dim3(768), lds2, st, w);
       else hipLaunchKernelGGL(k_conv_wgrad2<false>, grid, dim3(768), lds2, st, w);
-      launch_wgrad_reduce(P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT, st);
+      launch_wgrad_reduce(P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT, P->d_pair_off,
+                          P->wg.ny * P->wg.nchunks, st);
       if (w.cs_part)
         hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 31) / 32, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
                            dy_colsum_stride);
@@ -1769,7 +1818,8 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   else MI_LAUNCH_WG(8);
 #undef MI_LAUNCH_WG
 #undef MI_LAUNCH_WG_G
-  launch_wgrad_reduce(P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT, st);
+  launch_wgrad_reduce(P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT, P->d_pair_off,
+                          P->wg.ny * P->wg.nchunks, st);
   if (w.cs_part)
     hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 31) / 32, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
                        dy_colsum_stride);
