@@ -52,6 +52,12 @@ int64_t mi_gn_workspace_bytes(int N, int64_t V, int C);
 /* statistics -> scale_shift[N][C][2] (= gamma*rstd, beta-mean*gamma*rstd) and mean_rstd[N][G][2] */
 int mi_gn_stats(const void* x, int x_cstride, int N, int64_t V, int C, int G, float eps, const float* gamma, const float* beta,
                 float* scale_shift, float* mean_rstd, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+/* the same from per-channel partial sums produced elsewhere (mi_conv_fwd's out_stats): the tensor's channels are those of source a
+ * followed by those of source b (a channel concatenation, UNet:1263; Cb = 0: one source); partial_x: [N][Cx][chunks_x][2].
+ * A group must not straddle the two sources (MI_ERR_UNSUPPORTED). */
+int mi_gn_stats_from_partial(const float* partial_a, int chunks_a, int Ca, const float* partial_b, int chunks_b, int Cb, int N, int64_t V,
+                             int G, float eps, const float* gamma, const float* beta, float* scale_shift, float* mean_rstd,
+                             hipStream_t stream);
 /* y = (silu?)(x*scale+shift) */
 int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y, int y_cstride, int N, int64_t V, int C, int silu,
                 hipStream_t stream);
@@ -81,7 +87,11 @@ int mi_conv_pack_batch_destroy(mi_pack_batch* batch);
 /* y = conv(act(x)) + addvec + res;  act = GroupNorm affine (+SiLU) applied on the fly when scale_shift != NULL;
  * addvec: fp32 [Cout] (addvec_stride 0: bias) or N rows of pitch addvec_stride (bias + time-embedding projection, UNet:692-695) */
 int mi_conv_fwd(mi_conv_plan* plan, const void* x, int x_cstride, const float* scale_shift, int silu, const float* addvec,
-                int addvec_stride, const void* res, int res_cstride, void* y, int y_cstride, hipStream_t stream);
+                int addvec_stride, const void* res, int res_cstride, void* y, int y_cstride, float* out_stats, hipStream_t stream);
+/* out_stats (optional): the k3 s1 p1 3-D kernel also emits per-channel (sum, sum of squares) of its bf16 output, so the GroupNorm
+ * that consumes y (UNet:628, 648) needs no statistics pass over it: fp32 [N][Cout][chunks][2] with chunks = mi_conv_fwd_stats_chunks
+ * (0: this plan's forward cannot, pass NULL), every entry written.  Feed it to mi_gn_stats_from_partial. */
+int mi_conv_fwd_stats_chunks(const mi_conv_plan* plan);
 /* dx = conv_transpose(dy)  (gradient w.r.t. the ACTIVATED input) */
 int mi_conv_dgrad(mi_conv_plan* plan, const void* dy, int dy_cstride, void* dx, int dx_cstride, hipStream_t stream);
 /* dweight += x_act^T * dy   (fp32, torch layout; x_act recomputed from x with the same fused prologue).

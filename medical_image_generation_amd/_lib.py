@@ -31,6 +31,7 @@ _SIGS = {
     "mi_depth_to_space": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "mi_gn_workspace_bytes": [_i, _l, _i],
     "mi_gn_stats": [_p, _i, _i, _l, _i, _i, _f, _p, _p, _p, _p, _p, _l, _p],
+    "mi_gn_stats_from_partial": [_p, _i, _i, _p, _i, _i, _i, _l, _i, _f, _p, _p, _p, _p, _p],
     "mi_gn_apply": [_p, _i, _p, _p, _i, _i, _l, _i, _i, _p],
     "mi_gn_bwd": [_p, _i, _p, _i, _i, _l, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _l, _p],
     "mi_conv_plan_create": [C.POINTER(_p), _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
@@ -40,7 +41,8 @@ _SIGS = {
     "mi_conv_pack_batch_create": [C.POINTER(_p), C.POINTER(_p), C.POINTER(_p), _i],
     "mi_conv_pack_batch_run": [_p, _p],
     "mi_conv_pack_batch_destroy": [_p],
-    "mi_conv_fwd": [_p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p],
+    "mi_conv_fwd": [_p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p],
+    "mi_conv_fwd_stats_chunks": [_p],
     "mi_conv_dgrad": [_p, _p, _i, _p, _i, _p],
     "mi_conv_wgrad": [_p, _p, _i, _p, _i, _p, _i, _p, _p, _i, _p],
     "mi_linear_wgrad_bf16": [_p, _i, _i, _p, _i, _i, _l, _p, _p, _p],
@@ -71,7 +73,7 @@ _SIGS = {
     "mi_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _p, _p],
 }
 _RET = {"mi_gn_workspace_bytes": _l, "mi_attn_workspace_bytes": _l}
-_NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes", "mi_attn_supported", "mi_attn_workspace_bytes"}
+_NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes", "mi_attn_supported", "mi_attn_workspace_bytes", "mi_conv_fwd_stats_chunks"}
 
 _lib = None
 

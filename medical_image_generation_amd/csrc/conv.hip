@@ -1613,9 +1613,15 @@ int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
   return 0;
 }
 
+int mi_conv_fwd_stats_chunks(const mi_conv_plan* P) {
+  if (!P || !P->v27_fwd || P->N > 16) return 0;
+  return 4 * mi_conv27_grid_x(P->N * P->g_fwd.tilesD * P->g_fwd.tilesH * P->g_fwd.tilesW, P->fwd.ny);
+}
+
 int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const float* addvec, int addvec_stride,
-                const void* res, int res_cs, void* y, int y_cs, hipStream_t st) {
+                const void* res, int res_cs, void* y, int y_cs, float* out_stats, hipStream_t st) {
   if (!P || !x || !y || x_cs < P->Cin || y_cs < P->Cout) return MI_ERR_BAD_ARG;
+  if (out_stats && (!mi_conv_fwd_stats_chunks(P) || scale_shift || (x_cs & 7))) return MI_ERR_UNSUPPORTED;  // only the conv27 path emits them
   if ((P->c1_in || P->c1_out) && P->c1_packed && !scale_shift && !res) {
     int e = P->c1_in ? mi_launch_c1_expand(x, x_cs, P->d_c1w, addvec, addvec_stride, y, y_cs, P->N, P->Di, P->Hi, P->Wi, P->Cout, 0, st)
                      : mi_launch_c1_reduce(x, x_cs, P->d_c1w, addvec, addvec_stride, y, y_cs, P->N, P->Di, P->Hi, P->Wi, P->Cin, st);
@@ -1660,6 +1666,7 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
     a.res_bytes = rb < (1ll << 32) ? (unsigned)rb : 0u;
     const int64_t yb = (int64_t)P->N * P->Do * P->Ho * P->Wo * y_cs * 2;
     a.y_bytes = yb < (1ll << 32) ? (unsigned)yb : 0u;
+    a.stats = out_stats; a.stats_chunks = out_stats ? mi_conv_fwd_stats_chunks(P) : 0;
     return mi_launch_conv27(a, P->ncb_fwd, 0, ntiles, P->fwd.ny, st);
   }
   return launch_igemm_any(a, P->ncb_fwd, P->full27 ? 1 : 0, ntiles, P->fwd.ny, st);

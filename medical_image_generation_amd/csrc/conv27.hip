@@ -384,7 +384,52 @@ struct Epi {
   int n, d0, h0, w0;        // the tile being stored
   int active;               // a tile is pending
   u32x4 res[K<NCB>::PV];    // residual pieces (issued by inline asm: the compiler must not wait for them)
+  float sa[8], sq[8];       // a.stats: running sum / sum of squares of this lane's channel octet over the tiles of image sn
+  int sn;
 };
+// Fold the lanes that share a channel octet (they sit PV apart) and store this wave's chunk of image e.sn; resets the sums.
+template <int NCB>
+__device__ __forceinline__ void stats_flush(Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane) {
+  using KK = K<NCB>;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+#pragma unroll
+    for (int m = KK::PV; m < 64; m <<= 1) {
+      e.sa[j] += __shfl_xor(e.sa[j], m, 64);
+      e.sq[j] += __shfl_xor(e.sq[j], m, 64);
+    }
+  }
+  const int chunk = blockIdx.x * 4 + hl;
+  if (lane < KK::PV) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = y * NCB * 32 + lane * 8 + j;
+      if (c < a.Cout) *(float2*)(a.stats + (((int64_t)e.sn * a.Cout + c) * a.stats_chunks + chunk) * 2) = make_float2(e.sa[j], e.sq[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e.sa[j] = e.sq[j] = 0.f;
+}
+// every image's entry of this wave's chunk starts at zero (a workgroup may not see tiles of every image)
+template <int NCB>
+__device__ __forceinline__ void stats_zero(const ConvArgs& a, int y, int hl, int lane) {
+  using KK = K<NCB>;
+  const int chunk = blockIdx.x * 4 + hl;
+  if (lane < KK::PV)
+    for (int n = 0; n < a.N; ++n)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = y * NCB * 32 + lane * 8 + j;
+        if (c < a.Cout) *(float2*)(a.stats + (((int64_t)n * a.Cout + c) * a.stats_chunks + chunk) * 2) = make_float2(0.f, 0.f);
+      }
+}
+template <int NCB>
+__device__ __forceinline__ void stats_begin_tile(Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane) {
+  if (a.stats && e.sn != e.n) {  // wave-uniform
+    if (e.sn >= 0) stats_flush<NCB>(e, a, y, hl, lane);
+    e.sn = e.n;
+  }
+}
 template <int NCB>
 __device__ __forceinline__ void epi_geometry(const Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane, int p, int& v, int& sidx, bool& inside,
                                              unsigned& vox) {
@@ -427,6 +472,16 @@ __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char
 #pragma unroll
       for (int j = 0; j < 8; ++j) f.v[j] += rr.v[j];
       raw = pack8(f);
+    }
+    if (a.stats) {  // statistics of the ROUNDED values: what the consumer's GroupNorm will read
+      const F8 f = unpack8(raw);
+      const float mk = inside ? 1.f : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float t = mk * f.v[j];
+        e.sa[j] += t;
+        e.sq[j] = fmaf(t, f.v[j], e.sq[j]);
+      }
     }
     if (vec_ok) {  // always issued (masked lanes get an out-of-range offset): the store count is part of the vmcnt bookkeeping
       const unsigned off = inside ? (vox * (unsigned)a.y_cs + (unsigned)co) * 2u : 0xfffffff0u;
@@ -485,6 +540,10 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
   e.active = 0; e.n = e.d0 = e.h0 = e.w0 = 0;
 #pragma unroll
   for (int p = 0; p < KK::PV; ++p) e.res[p] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e.sa[j] = e.sq[j] = 0.f;
+  e.sn = -1;
+  if (a.stats) stats_zero<NCB>(a, y, hl, lane);
   int cur = 0;
   while (true) {
     seq_next(q, a, tile_step, tile_last);
@@ -492,6 +551,7 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
     // ---- top 0
     wait_vm<0>();  // group 1's weights are this wave's youngest operation
     __builtin_amdgcn_s_barrier();
+    if (epi) stats_begin_tile<NCB>(e, a, y, hl, lane);
     if (epi && has_res) epi_issue_res<NCB>(e, a, y, hl, lane);
     issue_next_A();
     issue_halo(a, lds, hp, hl, cur ^ 1, q.ntile >= 0, q.nn, q.nd0, q.nh0, q.nw0, q.nch * 32);
@@ -522,9 +582,11 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();  // final: the last tile's staging is complete
   if (e.active) {
+    stats_begin_tile<NCB>(e, a, y, hl, lane);
     if (has_res) { epi_issue_res<NCB>(e, a, y, hl, lane); wait_vm<0>(); }
     epi_process<0, KK::PV, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
   }
+  if (a.stats && e.sn >= 0) stats_flush<NCB>(e, a, y, hl, lane);
   wait_vm<0>();
 }
 
@@ -535,7 +597,10 @@ __global__ void __launch_bounds__(512, 2) k_conv27(ConvArgs a) {
   const int y = blockIdx.y;
   int tile_last, tile_step;
   const int tile0 = first_tile(a.ntiles, tile_last, tile_step);
-  if (tile0 >= tile_last) return;  // whole workgroup, before any barrier
+  if (tile0 >= tile_last) {  // whole workgroup, before any barrier
+    if (a.stats && wave >= 4) stats_zero<NCB>(a, y, wave - 4, lane);
+    return;
+  }
   if (wave < 4) compute_role<NCB, FLIP>(a, lds, y, wave, lane, tile0, tile_step, tile_last);
   else helper_role<NCB>(a, lds, y, wave - 4, lane, tile0, tile_step, tile_last);
 }
@@ -546,10 +611,8 @@ int launch27(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   a.ntiles = ntiles;
   static const char* dbg_env = getenv("MI_C27_DBG");
   a.dbg = dbg_env ? atoi(dbg_env) : 0;
-  int gx = (256 / ny) / 8 * 8;  // one workgroup per CU over all cout groups, a multiple of 8 (one slot set per XCD class)
-  if (gx < 8) gx = 8;
-  const int need = (ntiles + 7) / 8 * 8;
-  if (gx > need) gx = need;
+  const int gx = mi_conv27_grid_x(ntiles, ny);
+  if (a.stats && a.stats_chunks != 4 * gx) return MI_ERR_BAD_ARG;
   auto kern = k_conv27<NCB, FLIP>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -569,6 +632,13 @@ int launch27(ConvArgs a, int ntiles, int ny, hipStream_t st) {
 }
 
 }  // namespace
+
+int mi_conv27_grid_x(int ntiles, int ny) {
+  int gx = (256 / ny) / 8 * 8;  // one workgroup per CU over all cout groups, a multiple of 8 (one slot set per XCD class)
+  if (gx < 8) gx = 8;
+  const int need = (ntiles + 7) / 8 * 8;
+  return gx > need ? need : gx;
+}
 
 int mi_launch_conv27(const ConvArgs& a, int NCB, int flip, int ntiles, int ny, hipStream_t st) {
   if (a.g.TD != 4 || a.g.TH != 8 || a.g.TW != 8 || (a.x_cs & 7) || (a.Cin & 7)) return MI_ERR_BAD_ARG;

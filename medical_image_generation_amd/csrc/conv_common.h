@@ -36,6 +36,9 @@ struct ConvArgs {
   int perm16;  // weights packed with the conv27 row permutation (lane's 16 accumulator registers = 16 consecutive channels)
   int dbg;  // ablation knob (MI_IGEMM_DBG): 1 = stage only the first image, 2 = skip the MFMA loop, 3 = skip the epilogue
   unsigned x_bytes, wpk_bytes;  // sizes for the buffer descriptors (both < 4 GiB, checked on the host)
+  // conv27 forward only: per-channel (sum, sum of squares) of the bf16 OUTPUT for the GroupNorm that consumes it, laid out as the
+  // GroupNorm partials stats[n][c][chunk][2]; chunk = blockIdx.x * 4 + store wave, stats_chunks = 4 * gridDim.x.  null: none.
+  float* stats; int stats_chunks;
   Geom g;
 };
 
@@ -69,6 +72,7 @@ using namespace mi_conv;
 
 // conv27.hip: k3 s1 p1 3-D forward (flip = 0) / data gradient (flip = 1) on the 4x8x8 tile; a.g / tables as for the table-driven kernel
 int mi_launch_conv27(const ConvArgs& a, int NCB, int flip, int ntiles, int ny, hipStream_t st);
+int mi_conv27_grid_x(int ntiles, int ny);  // gridDim.x of that launch (4 statistics chunks per workgroup)
 // conv1x1.hip: 1x1x1 forward / data gradient as a streaming GEMM over voxels
 int mi_launch_conv1x1(const ConvArgs& a, int NCB, int ny, hipStream_t st);
 int mi_launch_wgrad1x1(const void* x, int x_cs, int Cin, const void* dy, int dy_cs, int Cout, int N, int64_t V, float* dw, float* colsum,

@@ -122,15 +122,21 @@ __device__ __forceinline__ void block_sum2_d(double& a, double& b, double* red) 
   b = (red[1] + red[3]) + (red[5] + red[7]);
 }
 
-__global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ partial, int chunks, int C, int G, int64_t V, float eps,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float* __restrict__ scale_shift, float* __restrict__ mean_rstd) {
+// (partial_b, chunks_b, Cb): optional second source holding the channels [Ca, Ca + Cb) -- see mi_gn_stats_from_partial
+__global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ partial, int chunks, int Ca, const float* __restrict__ partial_b,
+                                                     int chunks_b, int C, int G, int64_t V, float eps, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ scale_shift,
+                                                     float* __restrict__ mean_rstd) {
   __shared__ double red[8];
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   double s = 0.0, q = 0.0;
   {  // the group's channels are adjacent, so its chunks * cpg (sum, sumsq) pairs are ONE contiguous run
-    const float2* p = (const float2*)(partial + ((int64_t)n * C + g * cpg) * chunks * 2);
+    const float2* p = (const float2*)(partial + ((int64_t)n * Ca + g * cpg) * chunks * 2);
+    if (g * cpg >= Ca) {
+      p = (const float2*)(partial_b + ((int64_t)n * (C - Ca) + (g * cpg - Ca)) * chunks_b * 2);
+      chunks = chunks_b;
+    }
     for (int i = threadIdx.x; i < chunks * cpg; i += 256) {
       const float2 v = p[i];
       s += (double)v.x;
@@ -367,8 +373,19 @@ int mi_gn_stats(const void* x, int x_cstride, int N, int64_t V, int C, int G, fl
   int rows = kT / (C / 8);
   hipLaunchKernelGGL(k_gn_partial, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)x, x_cstride,
                      (float*)workspace, C, V, vc);
-  hipLaunchKernelGGL(k_gn_finalize, dim3(N * G), dim3(256), 0, st, (const float*)workspace, chunks, C, G, V, eps, gamma, beta,
-                     scale_shift, mean_rstd);
+  hipLaunchKernelGGL(k_gn_finalize, dim3(N * G), dim3(256), 0, st, (const float*)workspace, chunks, C, (const float*)nullptr, 0, C, G, V, eps,
+                     gamma, beta, scale_shift, mean_rstd);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+int mi_gn_stats_from_partial(const float* pa, int chunks_a, int Ca, const float* pb, int chunks_b, int Cb, int N, int64_t V, int G, float eps,
+                             const float* gamma, const float* beta, float* scale_shift, float* mean_rstd, hipStream_t st) {
+  const int C = Ca + Cb;
+  if (!pa || chunks_a <= 0 || Ca <= 0 || Cb < 0 || (Cb > 0 && (!pb || chunks_b <= 0)) || bad_c(C, G) || N <= 0 || V <= 0) return MI_ERR_BAD_ARG;
+  if (Cb > 0 && Ca % (C / G) != 0) return MI_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gn_finalize, dim3(N * G), dim3(256), 0, st, pa, chunks_a, Ca, pb, chunks_b, C, G, V, eps, gamma, beta, scale_shift,
+                     mean_rstd);
   MI_CHECK_LAUNCH();
   return 0;
 }

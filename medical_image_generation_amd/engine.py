@@ -28,6 +28,8 @@ import os as _os
 FUSE_PROLOGUE = _os.environ.get("MI_FUSE_PROLOGUE", "0") == "1"
 # Fused (flash-style) attention for head dims 32 / 64; MI_FLASH_ATTENTION=0 forces the materialised GEMM + softmax path.
 FLASH_ATTENTION = _os.environ.get("MI_FLASH_ATTENTION", "1") == "1"
+# GroupNorm statistics from the per-channel sums the producing conv's epilogue emits (no statistics pass over the tensor)
+FUSE_GN_STATS = ops.FUSE_GN_STATS
 
 
 # --------------------------------------------------------------------------------------------- parameters
@@ -113,6 +115,10 @@ class Ctx:
         # algorithmic matmul-class flops of this pass (2*MACs; torch.utils.flop_counter convention)
         self.flops_fwd = 0
         self.flops_bwd = 0
+        # id(tensor) -> (ChannelSums, tensor): per-channel sums the producing conv emitted, so that the GroupNorm consuming the
+        # tensor skips its statistics pass; id(concatenation) -> (a, b) lets a GroupNorm over a concat use both halves' sums
+        self.sums = {}
+        self.cat_parts = {}
 
     def count(self, fwd_flops, dgrad=True, wgrad=True):
         self.flops_fwd += fwd_flops
@@ -156,7 +162,19 @@ class PackBatch:
 # --------------------------------------------------------------------------------------------- ops
 def gn(ctx: Ctx, x, name, groups, eps):
     """Statistics only; the affine(+SiLU) is applied by the consumer (conv prologue or gn_apply)."""
-    st = ops.gn_stats(x, groups, eps, ctx.p(name + ".weight"), ctx.p(name + ".bias"))
+    gamma, beta = ctx.p(name + ".weight"), ctx.p(name + ".bias")
+    st = None
+    if FUSE_GN_STATS:
+        n, v = x.shape[0], x.shape[1] * x.shape[2] * x.shape[3]
+        ent, parts = ctx.sums.get(id(x)), ctx.cat_parts.get(id(x))
+        if ent is not None:
+            st = ops.gn_stats_from_sums(ent[0], None, n, v, groups, eps, gamma, beta)
+        elif parts is not None:
+            ea, eb = ctx.sums.get(id(parts[0])), ctx.sums.get(id(parts[1]))
+            if ea is not None and eb is not None:
+                st = ops.gn_stats_from_sums(ea[0], eb[0], n, v, groups, eps, gamma, beta)
+    if st is None:
+        st = ops.gn_stats(x, groups, eps, gamma, beta)
     st.name = name
     return st
 
@@ -183,7 +201,9 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
         xin, pn, ps = ops.gn_apply(x, norm, silu), None, False
     else:
         xin, pn, ps = x, norm, silu
-    y = plan.fwd(xin, pn, ps, addvec=av, res=res, out=out)  # out: channel-slice view of the consumer's concat buffer
+    y, sums = plan.fwd(xin, pn, ps, addvec=av, res=res, out=out, want_sums=True)  # out: channel-slice view of the consumer's concat buffer
+    if sums is not None:
+        ctx.sums[id(y)] = (sums, y)
     ctx.count(2 * y.numel() * cin * math.prod(kernel), dgrad=need_dx)
     if ctx.tape is not None:
         tape = ctx.tape
@@ -249,6 +269,7 @@ def concat(ctx: Ctx, a, b, buf=None):
         y = buf
     else:
         y = ops.concat_channels(a, b)
+    ctx.cat_parts[id(y)] = (a, b)
     if ctx.tape is not None:
         tape = ctx.tape
         ca, cb = a.shape[-1], b.shape[-1]

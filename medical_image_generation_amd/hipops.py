@@ -14,6 +14,9 @@ from . import _lib
 from ._lib import call, ptr
 
 BF16, F32 = torch.bfloat16, torch.float32
+import os as _os  # noqa: E402
+# convs emit the per-channel sums of their output for the consuming GroupNorm (conv27 epilogue); 0: separate statistics pass
+FUSE_GN_STATS = _os.environ.get("MI_FUSE_GN_STATS", "1") == "1"
 
 
 def _vox(t):  # [N, D, H, W, C] -> (N, V, C)
@@ -121,6 +124,28 @@ def gn_stats(x, groups, eps, gamma, beta) -> GNStats:
     return GNStats(ss, mr, groups)
 
 
+class ChannelSums:
+    """Per-channel (sum, sum of squares) partials of a tensor, [N][C][chunks][2] fp32, emitted by the conv that produced it."""
+    __slots__ = ("partial", "chunks", "channels")
+
+    def __init__(self, partial, chunks, channels):
+        self.partial, self.chunks, self.channels = partial, chunks, channels
+
+
+def gn_stats_from_sums(a: ChannelSums, b: ChannelSums | None, n, v, groups, eps, gamma, beta) -> GNStats | None:
+    """GroupNorm statistics of a tensor whose channels are those of `a` followed by those of `b` (or of `a` alone) without reading
+    the tensor.  None when a group would straddle the two sources."""
+    c = a.channels + (b.channels if b is not None else 0)
+    if b is not None and a.channels % (c // groups) != 0:
+        return None
+    dev = a.partial.device
+    ss = torch.empty((n, c, 2), dtype=F32, device=dev)
+    mr = torch.empty((n, groups, 2), dtype=F32, device=dev)
+    call("mi_gn_stats_from_partial", ptr(a.partial), a.chunks, a.channels, ptr(b.partial) if b is not None else None,
+         b.chunks if b is not None else 0, b.channels if b is not None else 0, n, v, groups, float(eps), ptr(gamma), ptr(beta), ptr(ss), ptr(mr))
+    return GNStats(ss, mr, groups)
+
+
 def gn_apply(x, st: GNStats, silu: bool):
     n, v, c = _vox(x)
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
@@ -154,6 +179,7 @@ class ConvPlan:
         od = (C.c_int * 3)()
         _lib.call_raw("mi_conv_plan_out_dims", self.handle, od)
         self.out_dims = tuple(od)
+        self.stats_chunks = int(_lib.call_raw("mi_conv_fwd_stats_chunks", self.handle))
 
     def __del__(self):
         try:
@@ -167,9 +193,10 @@ class ConvPlan:
         assert weight_f32.dtype == F32 and weight_f32.is_contiguous()
         call("mi_conv_pack_weights", self.handle, ptr(weight_f32))
 
-    def fwd(self, x, st: GNStats | None = None, silu=False, addvec=None, res=None, out=None):
+    def fwd(self, x, st: GNStats | None = None, silu=False, addvec=None, res=None, out=None, want_sums=False):
         """out: optional destination, a channel-slice view [N, D, H, W, Cout] of a wider channels-last buffer (the conv writes
-        straight into the skip-concat buffer of its consumer instead of being copied there)."""
+        straight into the skip-concat buffer of its consumer instead of being copied there).  want_sums: also return the
+        ChannelSums of y when this plan's kernel can emit them (else None): (y, sums)."""
         n, d, h, w, c = x.shape
         assert (n, (d, h, w), c) == (self.n, self.dims, self.cin), f"plan/input mismatch {x.shape} vs {self.n, self.dims, self.cin}"
         if out is None:
@@ -181,9 +208,12 @@ class ConvPlan:
         if addvec is not None and addvec.dim() == 2:  # [N, Cout] rows, possibly a column slice of a wider matrix
             assert addvec.shape == (n, self.cout) and addvec.stride(1) == 1
             av_stride = addvec.stride(0)
+        sums = None
+        if want_sums and FUSE_GN_STATS and st is None and self.stats_chunks > 0 and _cs(x) % 8 == 0:
+            sums = ChannelSums(torch.empty((n, self.cout, self.stats_chunks, 2), dtype=F32, device=x.device), self.stats_chunks, self.cout)
         call("mi_conv_fwd", self.handle, ptr(x), _cs(x), ptr(st.scale_shift) if st is not None else None, int(silu), ptr(addvec), av_stride,
-             ptr(res), _cs(res) if res is not None else 0, ptr(y), _cs(y))
-        return y
+             ptr(res), _cs(res) if res is not None else 0, ptr(y), _cs(y), ptr(sums.partial) if sums is not None else None)
+        return (y, sums) if want_sums else y
 
     def dgrad(self, dy):
         assert dy.shape == (self.n,) + self.out_dims + (self.cout,)

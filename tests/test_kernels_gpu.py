@@ -186,6 +186,38 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     check(dw2.cpu() - 1, wr.grad, 1e-2, "conv wgrad (batch-summed bias gradient variant)")
 
 
+@pytest.mark.parametrize("n,cin,cout,dims,groups", [(2, 32, 32, (8, 8, 8), 32), (1, 64, 96, (5, 9, 11), 32), (1, 32, 64, (8, 16, 16), 16),
+                                                    (3, 16, 48, (4, 6, 6), 8)])
+def test_conv_emits_groupnorm_sums(ops, n, cin, cout, dims, groups):
+    """The k3 s1 p1 forward kernel also emits per-channel sums of its (bf16) output; GroupNorm statistics built from them -- alone
+    and as the first / second half of a channel concatenation -- must equal the statistics pass over the stored tensor."""
+    x, w = rnd(n, cin, *dims), rnd(cout, cin, 3, 3, 3, scale=1.0 / math.sqrt(27 * cin))
+    bias, res = rnd(cout, seed=3), cl(rnd(n, cout, *dims, seed=8))
+    plan = ops.ConvPlan(n, dims, cin, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    assert plan.stats_chunks > 0
+    plan.pack(w.to(dev))
+    y, sums = plan.fwd(cl(x), addvec=bias.to(dev), res=res, want_sums=True)
+    assert sums is not None and torch.equal(y, plan.fwd(cl(x), addvec=bias.to(dev), res=res))
+    v = dims[0] * dims[1] * dims[2]
+    gamma, beta = (1 + 0.2 * rnd(cout, seed=5)).to(dev), (0.1 * rnd(cout, seed=6)).to(dev)
+    ref = ops.gn_stats(y, groups, 1e-6, gamma, beta)
+    got = ops.gn_stats_from_sums(sums, None, n, v, groups, 1e-6, gamma, beta)
+    check(got.scale_shift.cpu(), ref.scale_shift.cpu(), 1e-4, "scale/shift from conv sums")
+    check(got.mean_rstd.cpu(), ref.mean_rstd.cpu(), 1e-4, "mean/rstd from conv sums")
+    # concatenation [y | y2]: two sources with different chunk counts
+    plan2 = ops.ConvPlan(n, dims, cin, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    plan2.pack(rnd(32, cin, 3, 3, 3, seed=11, scale=0.1).to(dev))
+    y2, sums2 = plan2.fwd(cl(x), want_sums=True)
+    cat = ops.concat_channels(y, y2)
+    ct = cout + 32
+    g2 = next(g for g in range(ct // 2, 0, -1) if ct % g == 0 and cout % (ct // g) == 0)  # groups that do not straddle the halves
+    gam2, bet2 = torch.ones(cout + 32, device=dev), torch.zeros(cout + 32, device=dev)
+    ref2 = ops.gn_stats(cat, g2, 1e-6, gam2, bet2)
+    got2 = ops.gn_stats_from_sums(sums, sums2, n, v, g2, 1e-6, gam2, bet2)
+    assert got2 is not None
+    check(got2.scale_shift.cpu(), ref2.scale_shift.cpu(), 1e-4, "scale/shift from two sources")
+
+
 def test_conv_fused_prologue_epilogue(ops):
     """GroupNorm-affine + SiLU prologue, per-sample add vector (bias + temb) and residual in the epilogue."""
     n, cin, cout, dims = 2, 64, 32, (4, 8, 8)
