@@ -383,7 +383,7 @@ template <int NCB>
 struct Epi {
   int n, d0, h0, w0;        // the tile being stored
   int active;               // a tile is pending
-  u32x4 res[K<NCB>::PV];    // residual pieces (issued by inline asm: the compiler must not wait for them)
+  u32x4 res[K<NCB>::PV];    // residual pieces, loaded one tap group ahead of their use
   float sa[8], sq[8];       // a.stats: running sum / sum of squares of this lane's channel octet over the tiles of image sn
   int sn;
 };
@@ -442,16 +442,24 @@ __device__ __forceinline__ void epi_geometry(const Epi<NCB>& e, const ConvArgs& 
   inside = (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co + 8 <= a.Cout);
   vox = (unsigned)(((e.n * a.Do + od) * a.Ho + oh) * a.Wo + ow);
 }
+// The residual pieces are ordinary compiler-tracked buffer loads issued one tap group before their use, and only when there is a
+// residual; the compiler places the vmcnt waits itself (conservatively: the helper wave waits for them almost at once, about a
+// microsecond per tile of the layers that have a residual).  They used to be inline-asm loads that the compiler believed complete
+// at issue, consumed behind the manual vmcnt plan.  That is unsound: whenever the compiler copies or re-homes the destination
+// registers between issue and use (the phi copy behind a conditionally executed asm; live-range splits at 256 VGPRs; the home copy
+// of a tied "+v" operand) it reads them before the data has landed -- NaNs at realistic sizes only (tests/test_kernels_gpu.py::
+// test_conv_residual_at_size); 8^3 cases pass by luck because the loads return at once.
 template <int NCB>
-__device__ __forceinline__ void epi_issue_res(Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane) {
+__device__ __forceinline__ void epi_issue_res(Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane, bool enable) {
   using KK = K<NCB>;
-  const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res_bytes);
+  if (!enable) return;  // (a pending tracked load makes the compiler drain the DMA queue at its waits: none without a residual)
+  const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
 #pragma unroll
   for (int p = 0; p < KK::PV; ++p) {
     int v, sidx; bool inside; unsigned vox;
     epi_geometry<NCB>(e, a, y, hl, lane, p, v, sidx, inside, vox);
-    const unsigned off = inside ? (vox * (unsigned)a.res_cs + (unsigned)(y * NCB * 32 + sidx * 8)) * 2u : 0xfffffff0u;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(e.res[p]) : "v"(off), "s"(rres) : "memory");
+    const unsigned off = (inside && enable) ? (vox * (unsigned)a.res_cs + (unsigned)(y * NCB * 32 + sidx * 8)) * 2u : 0xfffffff0u;
+    e.res[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0));
   }
 }
 template <int P0, int CNT, int NCB>
@@ -467,7 +475,6 @@ __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char
     u32x4 raw = *(const u32x4*)(stg + v * KK::VOXP + ((sidx ^ (v & (KK::PV - 1))) * 16));
     const int co = y * NCB * 32 + sidx * 8;
     if (has_res) {
-      asm volatile("" : "+v"(e.res[p]));  // (landed: see the vmcnt bookkeeping above)
       F8 f = unpack8(raw), rr = unpack8(e.res[p]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) f.v[j] += rr.v[j];
@@ -552,7 +559,7 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
     wait_vm<0>();  // group 1's weights are this wave's youngest operation
     __builtin_amdgcn_s_barrier();
     if (epi) stats_begin_tile<NCB>(e, a, y, hl, lane);
-    if (epi && has_res) epi_issue_res<NCB>(e, a, y, hl, lane);
+    epi_issue_res<NCB>(e, a, y, hl, lane, epi && has_res);
     issue_next_A();
     issue_halo(a, lds, hp, hl, cur ^ 1, q.ntile >= 0, q.nn, q.nd0, q.nh0, q.nw0, q.nch * 32);
     // ---- tops 1 .. NG-2
@@ -583,7 +590,8 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
   __builtin_amdgcn_s_barrier();  // final: the last tile's staging is complete
   if (e.active) {
     stats_begin_tile<NCB>(e, a, y, hl, lane);
-    if (has_res) { epi_issue_res<NCB>(e, a, y, hl, lane); wait_vm<0>(); }
+    epi_issue_res<NCB>(e, a, y, hl, lane, has_res);
+    wait_vm<0>();
     epi_process<0, KK::PV, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
   }
   if (a.stats && e.sn >= 0) stats_flush<NCB>(e, a, y, hl, lane);

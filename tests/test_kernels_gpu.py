@@ -218,6 +218,29 @@ def test_conv_emits_groupnorm_sums(ops, n, cin, cout, dims, groups):
     check(got2.scale_shift.cpu(), ref2.scale_shift.cpu(), 1e-4, "scale/shift from two sources")
 
 
+@pytest.mark.parametrize("c", [32, 64])
+def test_conv_residual_at_size(ops, c):
+    """The residual pieces of the k3 s1 p1 kernel are loaded asynchronously a tap group ahead of their use; a load that is consumed
+    (or whose register is copied) before it has landed only shows at sizes where HBM latency is real -- 8^3 cases pass by luck.
+    2 x 64^3: 2048 tiles, both register-blocking variants (c = 32: one 32-channel block per wave, c = 64: two).  The epilogue adds
+    the residual to the bf16-rounded accumulator, so the result is bit-exact against conv-without-residual + residual."""
+    n, d = 2, 64
+    g = torch.Generator().manual_seed(c)
+    x = torch.randn(n, d, d, d, c, generator=g).to(dev, torch.bfloat16)
+    res = torch.randn(n, d, d, d, c, generator=g).to(dev, torch.bfloat16)
+    w = (torch.randn(c, c, 3, 3, 3, generator=g) / math.sqrt(27 * c)).to(dev)
+    bias = torch.randn(c, generator=g).to(dev)
+    plan = ops.ConvPlan(n, (d, d, d), c, c, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    plan.pack(w)
+    base = plan.fwd(x, addvec=bias)
+    want = (base.float() + res.float()).to(torch.bfloat16)
+    for with_sums in (False, True):
+        r = plan.fwd(x, addvec=bias, res=res, want_sums=with_sums)
+        y = r[0] if with_sums else r
+        assert torch.isfinite(y.float()).all()
+        assert torch.equal(y, want), f"residual epilogue differs (sums={with_sums}): {int((y != want).sum())} elements"
+
+
 def test_conv_fused_prologue_epilogue(ops):
     """GroupNorm-affine + SiLU prologue, per-sample add vector (bias + temb) and residual in the epilogue."""
     n, cin, cout, dims = 2, 64, 32, (4, 8, 8)
