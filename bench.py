@@ -172,6 +172,9 @@ def main():
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         use_graph = bool(ok.item())
     voxels = world * args.batch * args.size ** 3 * args.steps
+    # A step that computes garbage is not a measurement (and NaN operands even run FASTER: less MFMA power, higher clocks).
+    if not bool(torch.isfinite(loss.detach().float()).all()) or not bool(torch.isfinite(tr.arena.data).all()):
+        raise RuntimeError(f"bench: non-finite loss / parameters after the timed steps (loss = {float(loss)}): refusing to report a number")
 
     if rank == 0:
         # algorithmic flops of one step of this model (engine counters: 2*MACs, bwd = dgrad + wgrad)

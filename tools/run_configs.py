@@ -1,6 +1,7 @@
 """Run the other BASELINE.json configs through the fused HIP trainer and report ms/step (sanity + scale check).
 usage: python tools/run_configs.py c2|c3b|c5 [steps]"""
 import json
+import math
 import os
 import sys
 import time
@@ -39,6 +40,7 @@ def run_c3a():
         loss = tr.step_graph()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
+    assert math.isfinite(float(loss)), "non-finite loss: not a measurement"
     print(json.dumps({"config": "c3a", "ms_per_step": dt * 1e3, "voxels_per_s": 2 * 128 ** 3 / dt, "loss": float(loss),
                       "params": sum(p.numel() for p in net.parameters()), "model_flops_per_step_survey": 1.497e13,
                       "mfma_frac": 1.497e13 / dt / 2.5e15, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
@@ -85,6 +87,7 @@ dims = (shape[0],) + tuple(shape[2:]) + (shape[1],)
 net._run(c, torch.zeros(dims, dtype=torch.bfloat16, device=dev), t, need_dx=False)
 c.tape.fns.clear()
 fl = c.flops_fwd + c.flops_bwd
+assert math.isfinite(float(loss)), "non-finite loss: not a measurement"
 print(json.dumps({"config": which, "ms_per_step": dt * 1e3, "voxels_per_s": shape[0] * vox_per_sample / dt, "loss": float(loss),
                   "params": sum(p.numel() for p in net.parameters()), "model_flops_per_step": fl, "mfma_frac": fl / dt / 2.5e15,
                   "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
