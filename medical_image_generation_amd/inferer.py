@@ -1,0 +1,204 @@
+"""Reverse-diffusion sampling on the HIP path: the loop behind `inferer.sample(...)` in LDM.sample_images (train_ldm.py:332-366) and
+DDPM.sample_image (train_ddpm.py:238-246).
+
+The reference takes `DDPMScheduler`, `DiffusionInferer` and `LatentDiffusionInferer` from the third-party `generative` package
+(train_ldm.py:74, 102, 112), which is not under /root/reference; the classes here mirror the part of their interface those call
+sites use (same names, argument meaning, return values).  The scheduler arithmetic is the closed form of Ho et al. 2020 as upstream
+implements it, restated in oracle/step.py (`DDPMSchedule.step`): PARITY UNPINNED -- the reference holds no vectors for it; the
+tests pin the kernel against that restatement.
+
+One denoising step = UNet forward (no tape) + ONE fused update kernel (`mi_ddpm_step`: predicted x0, clip, posterior mean, noise;
+it also writes the next step's channels-last bf16 model input), captured once as a hipGraph and replayed per timestep -- the
+timestep is a device scalar the embedding and update kernels read, so all 1000 steps share one graph.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import engine as E
+from . import hipops as ops
+from ._lib import call, ptr
+
+F32 = torch.float32
+
+
+class DDPMScheduler:
+    """`generative.networks.schedulers.DDPMScheduler` as train_ldm.py:74 constructs it (variance_type "fixed_small")."""
+
+    def __init__(self, num_train_timesteps=1000, schedule="linear_beta", variance_type="fixed_small", clip_sample=True,
+                 prediction_type="epsilon", beta_start=1e-4, beta_end=2e-2):
+        if variance_type != "fixed_small":
+            raise NotImplementedError("only variance_type='fixed_small' (the upstream default the reference uses)")
+        if prediction_type != "epsilon":
+            raise NotImplementedError("only epsilon-prediction is on the HIP path (the reference's default, CFG:1012-1013)")
+        if schedule == "scaled_linear_beta":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=F32) ** 2
+        elif schedule == "linear_beta":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=F32)
+        else:
+            raise ValueError(f"unknown schedule {schedule}")
+        self.num_train_timesteps, self.prediction_type, self.clip_sample = num_train_timesteps, prediction_type, clip_sample
+        self.betas = betas
+        self.alphas = 1.0 - betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        acp, b = self.alphas_cumprod.double(), betas.double()
+        prev = torch.cat([torch.ones(1, dtype=torch.float64), acp[:-1]])
+        sigma = ((1 - prev) / (1 - acp) * b).clamp(min=1e-20).sqrt()
+        sigma[0] = 0.0  # no noise is added at t = 0
+        self._coef = torch.stack([1 / acp.sqrt(), (1 - acp).sqrt(), prev.sqrt() * b / (1 - acp), (1 - b).sqrt() * (1 - prev) / (1 - acp), sigma],
+                                 dim=1).float().contiguous()
+        self._coef_dev = None
+        self.set_timesteps(num_train_timesteps)
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        if num_inference_steps > self.num_train_timesteps:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than `self.num_train_timesteps`: "
+                             f"{self.num_train_timesteps}")
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        self.timesteps = (torch.arange(0, num_inference_steps) * ratio).round().flip(0).to(torch.int64)
+        if device is not None:
+            self.timesteps = self.timesteps.to(device)
+
+    def coefficients(self, device):
+        if self._coef_dev is None or self._coef_dev.device != torch.device(device):
+            self._coef_dev = self._coef.to(device)
+        return self._coef_dev
+
+    def add_noise(self, original_samples, noise, timesteps):
+        a = self.alphas_cumprod.to(original_samples.device)[timesteps]
+        shape = (-1,) + (1,) * (original_samples.ndim - 1)
+        return (a ** 0.5).reshape(shape) * original_samples + ((1 - a) ** 0.5).reshape(shape) * noise
+
+    def step(self, model_output, timestep, sample, generator=None):
+        """(pred_prev_sample, pred_original_sample) for fp32 NC[D]HW tensors -- the upstream signature; the fused loop of the inferers
+        below does not go through this (tensor-level) method."""
+        t = int(timestep)
+        k = self._coef[t].to(sample.device)
+        x0 = (sample - k[1] * model_output) * k[0]
+        if self.clip_sample:
+            x0 = x0.clamp(-1, 1)
+        prev = k[2] * x0 + k[3] * sample
+        if t > 0:
+            prev = prev + k[4] * torch.randn(sample.shape, generator=generator, device=sample.device, dtype=sample.dtype)
+        return prev, x0
+
+
+class _Loop:
+    """One captured denoising step, replayed over scheduler.timesteps."""
+
+    def __init__(self, model, scheduler, shape, device):
+        self.m, self.sch = model, scheduler
+        n, c = shape[0], shape[1]
+        sp = tuple(shape[2:])
+        self.v = 1
+        for s in sp:
+            self.v *= s
+        dims = (1,) * (3 - len(sp)) + sp
+        self.n, self.c = n, c
+        self.x = torch.empty(shape, dtype=F32, device=device)                    # the sample, fp32 NC[D]HW
+        self.x_cl = torch.empty((n,) + dims + (c,), dtype=torch.bfloat16, device=device)  # ... as the model reads it
+        self.z = torch.empty(shape, dtype=F32, device=device)
+        self.t = torch.zeros(1, dtype=torch.int64, device=device)
+        self.tn = torch.zeros(n, dtype=torch.int64, device=device)
+        self.coef = scheduler.coefficients(device)
+        self.arena = model.arena(device)
+        self.graph = None
+        self.keys = ()  # conv plans whose weights are packed: once per run(), not per step (the weights do not change while sampling)
+
+    def _step(self):
+        ctx = E.Ctx(self.arena, self.m._plans, grad_enabled=False, prepacked=self.keys)
+        eps = self.m._run(ctx, self.x_cl, self.tn, need_dx=False)
+        call("mi_ddpm_step", ptr(self.x), ptr(eps), ptr(self.z), ptr(self.coef), ptr(self.t), ptr(self.x_cl), self.n, self.c, self.v,
+             int(self.sch.clip_sample))
+
+    def run(self, input_noise, noises=None, generator=None, use_graph=True, on_step=None):
+        self.x.copy_(input_noise)
+        self.x_cl.copy_(ops.to_channels_last(self.x))
+        steps = [int(t) for t in self.sch.timesteps]
+        keep = self.x.clone()
+        if not self.m._plans or len(self.keys) != len(self.m._plans):
+            self.keys = ()
+            self.z.zero_()
+            self._step()  # first pass at this shape: creates the conv plans, every conv packs its own weights
+        self.keys = self.m.pack_all()  # current weights, one launch
+        if use_graph and self.graph is None and len(steps) > 2:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.z.zero_()
+                self._step()  # workspaces (hipMalloc) outside the capture
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self._step()
+        self.x.copy_(keep)
+        self.x_cl.copy_(ops.to_channels_last(self.x))
+        for i, t in enumerate(steps):
+            self.t.fill_(t)
+            self.tn.fill_(t)
+            if noises is not None:
+                self.z.copy_(noises[i])
+            elif t > 0:
+                self.z.normal_(generator=generator)
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._step()
+            if on_step is not None:
+                on_step(i, t, self.x)
+        return self.x.clone()
+
+
+class DiffusionInferer:
+    """`generative.inferers.DiffusionInferer(scheduler)`: `sample(input_noise, diffusion_model, scheduler)` (train_ddpm.py:243)."""
+
+    def __init__(self, scheduler):
+        self.scheduler = scheduler
+        self._loops = {}
+
+    def _loop(self, model, scheduler, shape, device):
+        key = (id(model), id(scheduler), tuple(shape))
+        if key not in self._loops:
+            self._loops[key] = _Loop(model, scheduler, tuple(shape), device)
+        return self._loops[key]
+
+    @torch.no_grad()
+    def sample(self, input_noise, diffusion_model, scheduler=None, save_intermediates=False, intermediate_steps=100, conditioning=None,
+               mode="crossattn", verbose=True, noises=None, generator=None, use_graph=True):
+        """noises: optional sequence with the z of every step (tests pin them); generator: torch generator for the per-step noise."""
+        if conditioning is not None:
+            raise NotImplementedError("conditioning is not on the HIP path (unused by the reference's configs)")
+        if not input_noise.is_cuda:
+            raise RuntimeError("medical_image_generation_amd runs on MI355X only: move the inputs to 'cuda'")
+        scheduler = scheduler or self.scheduler
+        inter = []
+
+        def on_step(i, t, x):
+            if save_intermediates and t % intermediate_steps == 0:
+                inter.append(x.clone())
+
+        loop = self._loop(diffusion_model, scheduler, input_noise.shape, input_noise.device)
+        image = loop.run(input_noise.float(), noises=noises, generator=generator, use_graph=use_graph, on_step=on_step)
+        return (image, inter) if save_intermediates else image
+
+
+class LatentDiffusionInferer(DiffusionInferer):
+    """`generative.inferers.LatentDiffusionInferer(scheduler, scale_factor)`: samples latents, then decodes
+    `autoencoder_model.decode_stage_2_outputs(latents / scale_factor)` (train_ldm.py:112, 362-364)."""
+
+    def __init__(self, scheduler, scale_factor=1.0):
+        super().__init__(scheduler)
+        self.scale_factor = scale_factor
+
+    @torch.no_grad()
+    def sample(self, input_noise, autoencoder_model, diffusion_model, scheduler=None, save_intermediates=False, intermediate_steps=100,
+               conditioning=None, mode="crossattn", verbose=True, noises=None, generator=None, use_graph=True):
+        out = super().sample(input_noise, diffusion_model, scheduler, save_intermediates, intermediate_steps, conditioning, mode, verbose,
+                             noises=noises, generator=generator, use_graph=use_graph)
+        latent, inter = out if save_intermediates else (out, None)
+        image = autoencoder_model.decode_stage_2_outputs(latent / self.scale_factor)
+        if save_intermediates:
+            return image, [autoencoder_model.decode_stage_2_outputs(z / self.scale_factor) for z in inter]
+        return image

@@ -41,6 +41,32 @@ class DDPMSchedule:
         sa, so = self._coef(timesteps, original_samples.ndim)
         return sa * original_samples + so * noise
 
+    def step_coefficients(self):
+        """Per-timestep constants of DDPMScheduler.step (third-party `generative.networks.schedulers.ddpm`, not under /root/reference:
+        restated from Ho et al. 2020 eq. 6-7 as upstream implements it; PARITY UNPINNED -- the reference holds no vectors for it).
+        Returns [T, 5]: 1/sqrt(acp_t), sqrt(1-acp_t), c_x0 = sqrt(acp_{t-1}) beta_t / (1-acp_t), c_xt = sqrt(alpha_t) (1-acp_{t-1}) / (1-acp_t),
+        sigma_t = sqrt(clamp((1-acp_{t-1})/(1-acp_t) beta_t, 1e-20)) for t > 0 and 0 at t = 0 ("fixed_small")."""
+        acp = self.alphas_cumprod.double()
+        betas = self.betas.double()
+        prev = torch.cat([torch.ones(1, dtype=torch.float64), acp[:-1]])
+        c_x0 = prev.sqrt() * betas / (1 - acp)
+        c_xt = (1 - betas).sqrt() * (1 - prev) / (1 - acp)
+        var = ((1 - prev) / (1 - acp) * betas).clamp(min=1e-20)
+        sigma = var.sqrt()
+        sigma[0] = 0.0
+        return torch.stack([1 / acp.sqrt(), (1 - acp).sqrt(), c_x0, c_xt, sigma], dim=1).float()
+
+    def step(self, model_output, timestep: int, sample, noise, clip_sample: bool = True):
+        """x_{t-1} and the predicted x_0 (epsilon prediction), noise = the z of this step."""
+        k = self.step_coefficients()[timestep]
+        x0 = (sample - k[1] * model_output) * k[0]
+        if clip_sample:
+            x0 = x0.clamp(-1, 1)
+        prev = k[2] * x0 + k[3] * sample
+        if timestep > 0:
+            prev = prev + k[4] * noise
+        return prev, x0
+
     def get_velocity(self, sample, noise, timesteps):
         sa, so = self._coef(timesteps, sample.ndim)
         return sa * noise - so * sample
