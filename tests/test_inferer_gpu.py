@@ -66,3 +66,34 @@ def test_sample_loop_matches_oracle(graph):
     err = float((got.cpu() - x).norm() / x.norm())
     print(f"\n[sample loop graph={graph}] rel-L2 after {len(steps)} steps: {err:.3e}")
     assert torch.isfinite(got).all() and err <= 3e-2  # bf16 UNet forward, 5 steps (same budget as the forward parity tests)
+
+
+def test_latent_inferer_decodes_through_the_autoencoder():
+    """LatentDiffusionInferer.sample = latent sample loop, then autoencoder.decode_stage_2_outputs(latents / scale_factor)
+    (train_ldm.py:112, 362-364)."""
+    from medical_image_generation_amd.autoencoderkl import AutoencoderKL
+    from medical_image_generation_amd.inferer import DDPMScheduler, DiffusionInferer, LatentDiffusionInferer
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    ae_c = cases.AEKL_CASES["aekl_c3a"]
+    ae = AutoencoderKL(**ae_c["kwargs"])
+    ae.load_state_dict(synth.state_dict({k: tuple(v.shape) for k, v in ae.state_dict().items()}, S))
+    ae = ae.cuda().eval()
+    kw = dict(spatial_dims=3, in_channels=8, out_channels=8, num_res_blocks=1, num_channels=(32, 64), attention_levels=(False, True),
+              num_head_channels=(0, 32), norm_num_groups=16, strides=[[1] * 3, [2] * 3], kernel_sizes=[[3] * 3] * 2, paddings=[[1] * 3] * 2)
+    net = DiffusionModelUNet(**kw)
+    net.load_state_dict(synth.state_dict({k: tuple(v.shape) for k, v in net.state_dict().items()}, S))
+    net = net.cuda().eval()
+    sch = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205)
+    sch.set_timesteps(4)
+    z = synth.tensor(S, "latent_noise", (1, 8, 8, 8, 8)).cuda()
+    zs = [synth.tensor(S, f"latent_z{i}", (1, 8, 8, 8, 8)).cuda() for i in range(4)]
+    scale = 0.7
+    lat = DiffusionInferer(sch).sample(z, net, sch, verbose=False, noises=zs)
+    img = LatentDiffusionInferer(sch, scale_factor=scale).sample(z, ae, net, sch, verbose=False, noises=zs)
+    with torch.no_grad():
+        want = ae.decode_stage_2_outputs(lat / scale)
+    assert img.shape == (1, 1, 32, 32, 32) and torch.isfinite(img).all()
+    assert torch.equal(img, want)
+    img2, inter = LatentDiffusionInferer(sch, scale_factor=scale).sample(z, ae, net, sch, save_intermediates=True, intermediate_steps=250,
+                                                                        verbose=False, noises=zs)
+    assert torch.equal(img2, want) and len(inter) == 4 and inter[-1].shape == img.shape

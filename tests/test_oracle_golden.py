@@ -147,3 +147,27 @@ def test_constructor_errors():
         nets.AutoencoderKL(3, num_channels=(30, 64), attention_levels=(False, False))
     with pytest.raises(ValueError):
         nets.timestep_embedding(torch.zeros(2, 2), 8)
+
+
+def test_reverse_step_closed_form_properties():
+    """DDPMSchedule.step (third-party closed form, parity unpinned): with the TRUE noise as model output the predicted x0 is x0, the
+    step from t = 0 returns it, and the posterior mean is the q(x_{t-1} | x_t, x_0) mean of Ho et al. 2020, eq. 7."""
+    import torch
+    from oracle import step
+    sch = step.DDPMSchedule()
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.rand(2, 1, 4, 4, 4, generator=g) * 2 - 1
+    eps = torch.randn(x0.shape, generator=g)
+    for t in (0, 1, 400, 999):
+        xt = sch.add_noise(x0, eps, torch.tensor([t, t]))
+        prev, px0 = sch.step(eps, t, xt, torch.zeros_like(x0), clip_sample=False)
+        assert torch.allclose(px0, x0, atol=2e-4)
+        acp = sch.alphas_cumprod.double()
+        a_prev = acp[t - 1] if t > 0 else torch.tensor(1.0, dtype=torch.float64)
+        beta = sch.betas.double()[t]
+        mean = (a_prev.sqrt() * beta / (1 - acp[t])) * x0.double() + ((1 - beta).sqrt() * (1 - a_prev) / (1 - acp[t])) * xt.double()
+        assert torch.allclose(prev.double(), mean, atol=2e-4)
+        if t == 0:
+            assert torch.allclose(prev, x0, atol=2e-4)
+    k = sch.step_coefficients()
+    assert k.shape == (1000, 5) and float(k[0, 4]) == 0.0 and bool((k[1:, 4] > 0).all())
