@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <unordered_map>
 #include <vector>
 
 #include "conv_common.h"
@@ -1092,23 +1093,61 @@ __global__ void __launch_bounds__(256) k_pack_weights(const float* __restrict__ 
     for (int i = threadIdx.x; i < c1n; i += 256) c1w[i] = w[i];
   pack_one(w, out, items, nfrags, out2, items2, nfrags2, Co_t, Ci_t, KT, blockIdx.x * 256 + threadIdx.x);
 }
-// every conv of a network in ONE launch (the per-conv launches are mostly launch floor: 67 convs, ~10 us each)
-struct PackDesc {
-  const float* w; u32x4* out; const int* items; u32x4* out2; const int* items2;
-  int nfrags, nfrags2, Co_t, Ci_t, KT;
-  int block0;  // first block of this conv
-  float* c1w; int c1n;  // fp32 copy for the single-channel kernels (null: none)
+// every conv of a network in ONE launch (the per-conv launches are mostly launch floor: 67 convs, ~10 us each):
+// The batch pack, staged through LDS.  Per fragment the gather above reads 8 floats per lane at a 108-byte stride (one tap of
+// 8 input channels): 41 M weights x 2 tables take 0.4 ms, bound by the texture addresser, not by HBM.  A GROUP is the set of
+// fragments that share (cout block of 32, cin block of 16) -- one per tap: its source is 32 (or, transposed for the data gradient,
+// 16) contiguous runs of `ni * KT` floats, read coalesced into LDS once, then every tap's fragment is assembled from LDS and stored
+// as a contiguous 1 KiB.
+struct PackGroup {
+  const float* w; u32x4* out;      // the conv's fp32 master weight, the fragment table (forward or data gradient) it packs into
+  int o0, i0;                      // first torch (out, in) channel of the block
+  int tr, perm;                    // transposed (data gradient); conv27 row permutation
+  int Co_t, Ci_t, KT;
+  int ntaps, tap_off;              // gtaps[tap_off + k] = {src_tap, fragment index}
+  float* c1w; int c1n;             // fp32 copy for the single-channel kernels (first group of such a conv; else null)
 };
-__global__ void __launch_bounds__(256) k_pack_batch(const PackDesc* __restrict__ descs, int n) {
-  int lo = 0, hi = n - 1;  // last descriptor with block0 <= blockIdx.x
-  while (lo < hi) {
-    const int mid = (lo + hi + 1) >> 1;
-    if (descs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+__global__ void __launch_bounds__(256) k_pack_groups(const PackGroup* __restrict__ groups, const int2* __restrict__ gtaps) {
+  extern __shared__ float sm[];
+  const PackGroup g = groups[blockIdx.x];
+  if (g.c1w)
+    for (int i = threadIdx.x; i < g.c1n; i += 256) g.c1w[i] = g.w[i];
+  const int no = g.tr ? 16 : 32, ni = g.tr ? 32 : 16;
+  const int run = ni * g.KT, pitch = run + 1;
+  const int nvalid = (g.Ci_t - g.i0 < ni ? (g.Ci_t - g.i0 > 0 ? g.Ci_t - g.i0 : 0) : ni) * g.KT;
+  {  // all rows as one flat index space, 8 independent loads in flight per thread (a row-by-row loop is one memory latency per row)
+    const int total = no * run;
+    const float* base = g.w + ((int64_t)g.o0 * g.Ci_t + g.i0) * g.KT;
+    const int64_t row_stride = (int64_t)g.Ci_t * g.KT;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * 256) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * 256, o = e / run, c = e - o * run;
+        v[u] = (e < total && g.o0 + o < g.Co_t && c < nvalid) ? base[o * row_stride + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * 256, o = e / run, c = e - o * run;
+        if (e < total) sm[o * pitch + c] = v[u];
+      }
+    }
   }
-  const PackDesc d = descs[lo];
-  if (d.c1w && (int)blockIdx.x == d.block0)
-    for (int i = threadIdx.x; i < d.c1n; i += 256) d.c1w[i] = d.w[i];
-  pack_one(d.w, d.out, d.items, d.nfrags, d.out2, d.items2, d.nfrags2, d.Co_t, d.Ci_t, d.KT, ((int)blockIdx.x - d.block0) * 256 + threadIdx.x);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rho = lane & 31, h = lane >> 5;
+  const int crow = g.perm ? 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3) : rho;
+  for (int ti = wave; ti < g.ntaps; ti += 4) {
+    const int2 tf = gtaps[g.tap_off + ti];
+    F8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = 8 * h + j;
+      const int o = g.tr ? k : crow, i = g.tr ? crow : k;
+      v.v[j] = tf.x >= 0 ? sm[o * pitch + i * g.KT + tf.x] : 0.f;
+    }
+    g.out[(int64_t)tf.y * 64 + lane] = pack8(v);
+  }
 }
 
 // dW[co][ci][tap] += sum_split part[split][pair][ti][co_l][ci_l];  uitems[(pair, ti)] = {src_tap, co0, ci0, _}
@@ -1574,41 +1613,85 @@ int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
 }
 
 struct mi_pack_batch {
-  PackDesc* d_descs = nullptr;
-  int n = 0, nblocks = 0;
+  PackGroup* d_groups = nullptr;
+  int2* d_gtaps = nullptr;
+  int ngroups = 0;
+  size_t lds = 0;
 };
+namespace {
+// groups of one fragment table: fragments keyed by (co0, ci0) in order of first appearance
+void add_groups(std::vector<PackGroup>& groups, std::vector<int2>& gtaps, const Tables& T, const float* w, const mi_conv_plan* P) {
+  std::unordered_map<int64_t, int> index;  // (co0, ci0) -> group
+  const size_t g0 = groups.size();
+  std::vector<std::vector<int2>> taps;
+  for (int f = 0; f < T.nfrags; ++f) {
+    const int* it = &T.frag_items[(size_t)f * 4];
+    const int64_t key = ((int64_t)it[1] << 32) | (unsigned)it[2];
+    auto found = index.find(key);
+    int gi = found == index.end() ? -1 : found->second;
+    if (gi < 0) {
+      gi = (int)taps.size();
+      index.emplace(key, gi);
+      taps.emplace_back();
+      PackGroup g;
+      memset(&g, 0, sizeof(g));
+      g.w = w; g.out = T.d_wpk;
+      g.tr = it[3] & 1; g.perm = (it[3] >> 1) & 1;
+      g.o0 = g.tr ? it[2] : it[1];   // torch out channel: kernel cin when transposed
+      g.i0 = g.tr ? it[1] : it[2];
+      g.Co_t = P->Cout; g.Ci_t = P->Cin; g.KT = P->KT;
+      groups.push_back(g);
+    }
+    taps[(size_t)gi].push_back(int2{it[0], f});
+  }
+  for (size_t k = 0; k < taps.size(); ++k) {
+    groups[g0 + k].ntaps = (int)taps[k].size();
+    groups[g0 + k].tap_off = (int)gtaps.size();
+    gtaps.insert(gtaps.end(), taps[k].begin(), taps[k].end());
+  }
+}
+}  // namespace
 int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, const float* const* weights, int n) {
   if (!out || !plans || !weights || n <= 0) return MI_ERR_BAD_ARG;
-  std::vector<PackDesc> h((size_t)n);
-  int blocks = 0;
+  std::vector<PackGroup> groups;
+  std::vector<int2> gtaps;
+  size_t lds = 0;
   for (int i = 0; i < n; ++i) {
     mi_conv_plan* P = plans[i];
     if (!P || !weights[i]) return MI_ERR_BAD_ARG;
     P->c1_packed = true;
-    PackDesc& d = h[(size_t)i];
-    d.w = weights[i]; d.out = P->fwd.d_wpk; d.items = P->fwd.d_items; d.out2 = P->dg.d_wpk; d.items2 = P->dg.d_items;
-    d.nfrags = P->fwd.nfrags; d.nfrags2 = P->dg.nfrags; d.Co_t = P->Cout; d.Ci_t = P->Cin; d.KT = P->KT;
-    d.block0 = blocks;
-    d.c1w = P->d_c1w; d.c1n = P->d_c1w ? 27 * P->Cin * P->Cout : 0;
-    blocks += ((P->fwd.nfrags + P->dg.nfrags) * 64 + 255) / 256;
+    const size_t g0 = groups.size();
+    add_groups(groups, gtaps, P->fwd, weights[i], P);
+    add_groups(groups, gtaps, P->dg, weights[i], P);
+    if (P->d_c1w && groups.size() > g0) { groups[g0].c1w = P->d_c1w; groups[g0].c1n = 27 * P->Cin * P->Cout; }
+    const size_t need = sizeof(float) * 32 * (size_t)(16 * P->KT + 1) > sizeof(float) * 16 * (size_t)(32 * P->KT + 1)
+                            ? sizeof(float) * 32 * (size_t)(16 * P->KT + 1) : sizeof(float) * 16 * (size_t)(32 * P->KT + 1);
+    if (need > lds) lds = need;
   }
+  if (lds > 64 * 1024) return MI_ERR_UNSUPPORTED;
   mi_pack_batch* B = new mi_pack_batch();
-  B->n = n; B->nblocks = blocks;
-  if (hipMalloc((void**)&B->d_descs, sizeof(PackDesc) * (size_t)n) != hipSuccess) { delete B; return (int)hipErrorOutOfMemory; }
-  hipError_t e = hipMemcpy(B->d_descs, h.data(), sizeof(PackDesc) * (size_t)n, hipMemcpyHostToDevice);
-  if (e != hipSuccess) { (void)hipFree(B->d_descs); delete B; return (int)e; }
+  B->ngroups = (int)groups.size(); B->lds = lds;
+  if (hipMalloc((void**)&B->d_groups, sizeof(PackGroup) * (groups.size() ? groups.size() : 1)) != hipSuccess ||
+      hipMalloc((void**)&B->d_gtaps, sizeof(int2) * (gtaps.size() ? gtaps.size() : 1)) != hipSuccess) {
+    mi_conv_pack_batch_destroy(B);
+    return (int)hipErrorOutOfMemory;
+  }
+  hipError_t e = hipMemcpy(B->d_groups, groups.data(), sizeof(PackGroup) * groups.size(), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(B->d_gtaps, gtaps.data(), sizeof(int2) * gtaps.size(), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { mi_conv_pack_batch_destroy(B); return (int)e; }
   *out = B;
   return 0;
 }
 int mi_conv_pack_batch_run(mi_pack_batch* B, hipStream_t st) {
   if (!B) return MI_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_pack_batch, dim3(B->nblocks), dim3(256), 0, st, B->d_descs, B->n);
+  if (B->ngroups) hipLaunchKernelGGL(k_pack_groups, dim3(B->ngroups), dim3(256), B->lds, st, B->d_groups, B->d_gtaps);
   MI_CHECK_LAUNCH();
   return 0;
 }
 int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
   if (!B) return 0;
-  if (B->d_descs) (void)hipFree(B->d_descs);
+  if (B->d_groups) (void)hipFree(B->d_groups);
+  if (B->d_gtaps) (void)hipFree(B->d_gtaps);
   delete B;
   return 0;
 }
