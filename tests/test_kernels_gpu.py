@@ -155,6 +155,9 @@ CONV_CASES = [
     (1, 64, 64, (1, 20, 12), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     (1, 16, 48, (4, 6, 6), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
     (1, 256, 128, (4, 4, 4), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
+    # 80 tiles x 2 channel blocks: the only case here large enough for the 64-channels-per-workgroup variants of the k3 s1 kernels
+    # (forward AND data gradient) -- every smaller case runs the 32-channel variants
+    (1, 128, 128, (20, 32, 32), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
 ]
 
 
