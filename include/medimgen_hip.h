@@ -54,7 +54,7 @@ int mi_gn_stats(const void* x, int x_cstride, int N, int64_t V, int C, int G, fl
                 float* scale_shift, float* mean_rstd, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 /* the same from per-channel partial sums produced elsewhere (mi_conv_fwd's out_stats): the tensor's channels are those of source a
  * followed by those of source b (a channel concatenation, UNet:1263; Cb = 0: one source); partial_x: [N][Cx][chunks_x][2].
- * A group must not straddle the two sources (MI_ERR_UNSUPPORTED). */
+ * A group may straddle the two sources. */
 int mi_gn_stats_from_partial(const float* partial_a, int chunks_a, int Ca, const float* partial_b, int chunks_b, int Cb, int N, int64_t V,
                              int G, float eps, const float* gamma, const float* beta, float* scale_shift, float* mean_rstd,
                              hipStream_t stream);

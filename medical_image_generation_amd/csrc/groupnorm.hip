@@ -131,16 +131,23 @@ __global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ p
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   double s = 0.0, q = 0.0;
-  {  // the group's channels are adjacent, so its chunks * cpg (sum, sumsq) pairs are ONE contiguous run
-    const float2* p = (const float2*)(partial + ((int64_t)n * Ca + g * cpg) * chunks * 2);
-    if (g * cpg >= Ca) {
-      p = (const float2*)(partial_b + ((int64_t)n * (C - Ca) + (g * cpg - Ca)) * chunks_b * 2);
-      chunks = chunks_b;
-    }
-    for (int i = threadIdx.x; i < chunks * cpg; i += 256) {
+  {  // the group's channels are adjacent: its (sum, sumsq) pairs are one contiguous run per source (a group may straddle the two)
+    const int c0 = g * cpg, c1 = c0 + cpg;
+    const int a0 = c0 < Ca ? c0 : Ca, a1 = c1 < Ca ? c1 : Ca;  // channels [a0, a1) come from source a, [b0, b1) from source b
+    const float2* p = (const float2*)(partial + ((int64_t)n * Ca + a0) * chunks * 2);
+    for (int i = threadIdx.x; i < (a1 - a0) * chunks; i += 256) {
       const float2 v = p[i];
       s += (double)v.x;
       q += (double)v.y;
+    }
+    if (c1 > Ca) {
+      const int b0 = (c0 > Ca ? c0 : Ca) - Ca, b1 = c1 - Ca;
+      const float2* pb = (const float2*)(partial_b + ((int64_t)n * (C - Ca) + b0) * chunks_b * 2);
+      for (int i = threadIdx.x; i < (b1 - b0) * chunks_b; i += 256) {
+        const float2 v = pb[i];
+        s += (double)v.x;
+        q += (double)v.y;
+      }
     }
   }
   block_sum2_d(s, q, red);
@@ -383,7 +390,6 @@ int mi_gn_stats_from_partial(const float* pa, int chunks_a, int Ca, const float*
                              const float* gamma, const float* beta, float* scale_shift, float* mean_rstd, hipStream_t st) {
   const int C = Ca + Cb;
   if (!pa || chunks_a <= 0 || Ca <= 0 || Cb < 0 || (Cb > 0 && (!pb || chunks_b <= 0)) || bad_c(C, G) || N <= 0 || V <= 0) return MI_ERR_BAD_ARG;
-  if (Cb > 0 && Ca % (C / G) != 0) return MI_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(k_gn_finalize, dim3(N * G), dim3(256), 0, st, pa, chunks_a, Ca, pb, chunks_b, C, G, V, eps, gamma, beta, scale_shift,
                      mean_rstd);
   MI_CHECK_LAUNCH();

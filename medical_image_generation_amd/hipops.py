@@ -134,10 +134,8 @@ class ChannelSums:
 
 def gn_stats_from_sums(a: ChannelSums, b: ChannelSums | None, n, v, groups, eps, gamma, beta) -> GNStats | None:
     """GroupNorm statistics of a tensor whose channels are those of `a` followed by those of `b` (or of `a` alone) without reading
-    the tensor.  None when a group would straddle the two sources."""
+    the tensor."""
     c = a.channels + (b.channels if b is not None else 0)
-    if b is not None and a.channels % (c // groups) != 0:
-        return None
     dev = a.partial.device
     ss = torch.empty((n, c, 2), dtype=F32, device=dev)
     mr = torch.empty((n, groups, 2), dtype=F32, device=dev)
