@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, PITCH = 40;  // PITCH in bf16 elements (80 bytes)
+constexpr int BK = 32, PITCH = 40;  // PITCH in bf16 elements (80 bytes)
 
 struct GemmArgs {
   const bf16* A;
@@ -26,7 +26,11 @@ struct GemmArgs {
   int out_f32, accumulate;
 };
 
+// WT = MFMA tiles per wave and dimension: 2 -> 128x128 block tile, 1 -> 64x64 (projections of a 16^3 level, M = 4096, N = 256:
+// 64 workgroups of 128x128 would leave three quarters of the chip idle)
+template <int WT>
 __global__ void __launch_bounds__(256) k_gemm_nt(GemmArgs p) {
+  constexpr int BM = 64 * WT, BN = 64 * WT;
   __shared__ __attribute__((aligned(16))) bf16 lds[2][2][BM * PITCH];  // [buf][A|B][row][PITCH]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -36,18 +40,18 @@ __global__ void __launch_bounds__(256) k_gemm_nt(GemmArgs p) {
   const bf16* B = p.B + z1 * p.sB1 + z2 * p.sB2;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
-  // staging map: 512 16-byte pieces per operand tile, 2 per thread
-  int prow[2], pk[2];
+  // staging map: 256 * WT 16-byte pieces per operand tile, WT per thread
+  int prow[WT], pk[WT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < WT; ++i) {
     int pc = tid + 256 * i;
     prow[i] = pc >> 2;
     pk[i] = (pc & 3) * 8;
   }
-  u32x4 ra[2], rb[2];
+  u32x4 ra[WT], rb[WT];
   auto gload = [&](int k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WT; ++i) {
       u32x4 zero = {0u, 0u, 0u, 0u};
       int k = k0 + pk[i];
       int am = m0 + prow[i], bn = n0 + prow[i];
@@ -57,17 +61,17 @@ __global__ void __launch_bounds__(256) k_gemm_nt(GemmArgs p) {
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WT; ++i) {
       *(u32x4*)(&lds[buf][0][prow[i] * PITCH + pk[i]]) = ra[i];
       *(u32x4*)(&lds[buf][1][prow[i] * PITCH + pk[i]]) = rb[i];
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[WT][WT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < WT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < WT; ++b)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
@@ -80,16 +84,16 @@ __global__ void __launch_bounds__(256) k_gemm_nt(GemmArgs p) {
     if (kt + 1 < nk) gload((kt + 1) * BK);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[2], fb[2];
+      bf16x8 fa[WT], fb[WT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        fa[i] = *(const bf16x8*)(&lds[buf][0][(wm * 64 + i * 32 + r) * PITCH + ks * 16 + h * 8]);
-        fb[i] = *(const bf16x8*)(&lds[buf][1][(wn * 64 + i * 32 + r) * PITCH + ks * 16 + h * 8]);
+      for (int i = 0; i < WT; ++i) {
+        fa[i] = *(const bf16x8*)(&lds[buf][0][(wm * 32 * WT + i * 32 + r) * PITCH + ks * 16 + h * 8]);
+        fb[i] = *(const bf16x8*)(&lds[buf][1][(wn * 32 * WT + i * 32 + r) * PITCH + ks * 16 + h * 8]);
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < WT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < WT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
     }
     if (kt + 1 < nk) lstore(buf ^ 1);
     __syncthreads();
@@ -99,15 +103,15 @@ __global__ void __launch_bounds__(256) k_gemm_nt(GemmArgs p) {
   const int64_t coff = z1 * p.sC1 + z2 * p.sC2;
   const int64_t roff = z1 * p.sR1 + z2 * p.sR2;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < WT; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int n = n0 + wn * 64 + b * 32 + r;
+    for (int b = 0; b < WT; ++b) {
+      const int n = n0 + wn * 32 * WT + b * 32 + r;
       if (n >= p.N) continue;
       const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int m = m0 + wm * 32 * WT + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m >= p.M) continue;
         float v = acc[a][b][e] * p.alpha + bv;
         if (p.R) v += bf2f(p.R[roff + (int64_t)m * p.ldr + n]);
@@ -187,7 +191,10 @@ int mi_gemm_nt_bf16(const void* A, int lda, int64_t sA1, int64_t sA2, const void
   p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.ldr = ldr;
   p.Z2 = Z2; p.sA1 = sA1; p.sA2 = sA2; p.sB1 = sB1; p.sB2 = sB2; p.sC1 = sC1; p.sC2 = sC2; p.sR1 = sR1; p.sR2 = sR2;
   p.alpha = alpha; p.out_f32 = out_f32; p.accumulate = accumulate;
-  hipLaunchKernelGGL(k_gemm_nt, dim3(ceil_div(N, BN), ceil_div(M, BM), Z), dim3(256), 0, st, p);
+  if ((int64_t)ceil_div(N, 128) * ceil_div(M, 128) * Z < 256)  // fewer workgroups than CUs: quarter-size tiles
+    hipLaunchKernelGGL(k_gemm_nt<1>, dim3(ceil_div(N, 64), ceil_div(M, 64), Z), dim3(256), 0, st, p);
+  else
+    hipLaunchKernelGGL(k_gemm_nt<2>, dim3(ceil_div(N, 128), ceil_div(M, 128), Z), dim3(256), 0, st, p);
   MI_CHECK_LAUNCH();
   return 0;
 }
