@@ -136,15 +136,18 @@ __global__ void k_space_depth(const bf16* __restrict__ in, bf16* __restrict__ ou
 
 // ---------------------------------------------------------------- q-sample and MSE at the model boundary
 // x_t = a[n] * x0 + b[n] * noise, NCDHW fp32 in, NDHWC bf16 out (T-LDM:160; closed form oracle/step.py)
+// velocity (optional, fp32 NCDHW): the v-prediction target a * noise - b * x0 (scheduler.get_velocity, T-LDM:163-165)
 __global__ void k_qsample(const float* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ sqrt_acp,
-                          const float* __restrict__ sqrt_1macp, const int64_t* __restrict__ t, bf16* __restrict__ out, int C,
-                          int64_t V, int64_t total) {
+                          const float* __restrict__ sqrt_1macp, const int64_t* __restrict__ t, bf16* __restrict__ out,
+                          float* __restrict__ velocity, int C, int64_t V, int64_t total) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t n = i / V, v = i - n * V;
     float a = sqrt_acp[t[n]], b = sqrt_1macp[t[n]];
     for (int c = 0; c < C; ++c) {
       int64_t s = (n * C + c) * V + v;
-      out[i * C + c] = f2bf(a * x0[s] + b * noise[s]);
+      const float xv = x0[s], nv = noise[s];
+      out[i * C + c] = f2bf(a * xv + b * nv);
+      if (velocity) velocity[s] = a * nv - b * xv;
     }
   }
 }
@@ -432,10 +435,11 @@ int mi_depth_to_space(const void* in, void* out, int N, int D, int H, int W, int
   return 0;
 }
 int mi_qsample(const float* x0, const float* noise, const float* sqrt_acp, const float* sqrt_1macp, const int64_t* t, void* out,
-               int N, int C, int64_t V, hipStream_t st) {
+               float* velocity, int N, int C, int64_t V, hipStream_t st) {
   int64_t total = (int64_t)N * V;
   if (total <= 0) return MI_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_qsample, dim3(grid_for(total)), dim3(kThreads), 0, st, x0, noise, sqrt_acp, sqrt_1macp, t, (bf16*)out, C, V, total);
+  hipLaunchKernelGGL(k_qsample, dim3(grid_for(total)), dim3(kThreads), 0, st, x0, noise, sqrt_acp, sqrt_1macp, t, (bf16*)out, velocity, C, V,
+                     total);
   MI_CHECK_LAUNCH();
   return 0;
 }

@@ -37,8 +37,8 @@ class DDPMSchedule:
             betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=F32)
         else:
             raise ValueError(f"unknown schedule {schedule}")
-        if prediction_type != "epsilon":
-            raise NotImplementedError("only epsilon-prediction is on the HIP path (the reference's default, CFG:1012-1013)")
+        if prediction_type not in ("epsilon", "v_prediction"):
+            raise ValueError(f"unknown prediction_type {prediction_type} (train_ldm.py:163-166 knows 'epsilon' and 'v_prediction')")
         acp = torch.cumprod(1.0 - betas, dim=0)
         self.num_train_timesteps, self.prediction_type = num_train_timesteps, prediction_type
         self.sqrt_acp = acp.sqrt().to(device)
@@ -148,11 +148,14 @@ class DDPMTrainer(_ArenaTrainer):
             v *= s
         dims = (1,) * (3 - sd) + sp
         x_t = torch.empty((n,) + dims + (c,), dtype=torch.bfloat16, device=x0.device)
-        call("mi_qsample", ptr(x0), ptr(noise), ptr(self.schedule.sqrt_acp), ptr(self.schedule.sqrt_1macp), ptr(timesteps), ptr(x_t), n, c, v)
+        vpred = self.schedule.prediction_type == "v_prediction"  # target = scheduler.get_velocity(x0, noise, t), T-LDM:163-165
+        target = torch.empty_like(noise) if vpred else noise
+        call("mi_qsample", ptr(x0), ptr(noise), ptr(self.schedule.sqrt_acp), ptr(self.schedule.sqrt_1macp), ptr(timesteps), ptr(x_t),
+             ptr(target) if vpred else None, n, c, v)
         ctx = E.Ctx(a, m._plans, grad_enabled=True, prepacked=m.pack_all())
         pred = m._run(ctx, x_t, timesteps, need_dx=False)
         dpred = torch.empty_like(pred)
-        call("mi_mse_fwd_bwd", ptr(pred), ptr(noise), ptr(dpred), ptr(self.loss), n, pred.shape[-1], v, 1.0)
+        call("mi_mse_fwd_bwd", ptr(pred), ptr(target), ptr(dpred), ptr(self.loss), n, pred.shape[-1], v, 1.0)
         ctx.tape.backward(pred, dpred)
         ctx.tape.grads.clear(), ctx.tape.keep.clear()
 

@@ -278,9 +278,12 @@ def test_train_glue(ops):
     out = torch.empty((n, *dims, c), dtype=torch.bfloat16, device=dev)
     sa, so = acp.sqrt().to(dev), (1 - acp).sqrt().to(dev)
     x0d, nd, td = x0.to(dev), noise.to(dev), t.to(dev)  # keep alive: calls are asynchronous
-    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(out), n, c, v)
+    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(out), None, n, c, v)
     ref = acp[t].sqrt().view(n, 1, 1, 1, 1) * x0 + (1 - acp[t]).sqrt().view(n, 1, 1, 1, 1) * noise
     check(cf(out), ref, 1e-2, "qsample")
+    vel = torch.empty_like(x0d)  # v-prediction target (scheduler.get_velocity, T-LDM:163-165)
+    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(out), ptr(vel), n, c, v)
+    check(vel.cpu(), acp[t].sqrt().view(n, 1, 1, 1, 1) * noise - (1 - acp[t]).sqrt().view(n, 1, 1, 1, 1) * x0, 1e-6, "velocity target")
     pred = rnd(n, c, *dims, seed=2)
     pr = pred.clone().requires_grad_(True)
     loss_ref = F.mse_loss(pr, noise)

@@ -115,3 +115,26 @@ def test_ae_three_train_steps(name, graph):
     print(f"  update cosine {cos:.4f}  |upd| ref {float(upd_ref.norm()):.4f} hip {float(upd_hip.norm()):.4f}")
     # L1's sign() gradient flips on bf16-level differences of recon - x, and Adam turns every flip into a full +-lr step
     assert cos >= 0.85 and abs(float(upd_hip.norm()) / float(upd_ref.norm()) - 1) <= 0.05
+
+
+def test_v_prediction_step_matches_oracle():
+    """prediction_type = "v_prediction" (train_ldm.py:163-165): the target is scheduler.get_velocity(x0, noise, t)."""
+    from medical_image_generation_amd.trainer import DDPMSchedule, DDPMTrainer
+    c, ref, net = _nets("unet3d")
+    tr = DDPMTrainer(net, lr=cases.STEP_LR, optimizer="AdamW", max_grad_norm=1.0, schedule=DDPMSchedule(prediction_type="v_prediction"))
+    sched = step.DDPMSchedule(prediction_type="v_prediction")
+    x0 = synth.ellipsoid_volume(S, "x0", c["shape"])
+    noise = synth.tensor(S, "noise0", c["shape"])
+    t = torch.tensor(c["timesteps"])
+    loss_ref, _ = step.ddpm_loss(ref, sched, x0, noise, t)
+    loss_ref.backward()
+    tr.forward_backward(x0.cuda(), noise.cuda(), t.cuda())
+    assert abs(float(tr.loss) - float(loss_ref)) <= 1e-2 * abs(float(loss_ref))
+    names = [n for n, p in ref.named_parameters() if p.grad is not None]
+    g_ref = torch.cat([dict(ref.named_parameters())[n].grad.flatten() for n in names])
+    g_hip = torch.cat([tr.arena.gview(n).cpu().flatten() for n in names])
+    err = float((g_hip - g_ref).norm() / g_ref.norm())
+    print(f"\n[v-prediction] loss {float(tr.loss):.6f} vs {float(loss_ref):.6f}, global gradient rel-L2 {err:.3e}")
+    assert err <= 4e-2
+    with pytest.raises(ValueError):
+        DDPMSchedule(prediction_type="sample")
