@@ -153,7 +153,8 @@ int mi_qsample(const float* x0, const float* noise, const float* sqrt_alphas_cum
 /* one reverse step of DDPMScheduler.step (third-party `generative`; epsilon prediction, "fixed_small" variance) as the inferers'
  * sample loops call it (train_ldm.py:349-365, train_ddpm.py:238-246): x (fp32 NCDHW) is updated in place and also written as the
  * next model input x_cl (NDHWC bf16, may be NULL); eps = model output (NDHWC bf16); noise fp32 NCDHW;
- * coef: [T][5] = 1/sqrt(acp_t), sqrt(1-acp_t), c_x0, c_xt, sigma_t (0 at t = 0); t: device pointer to the (single) timestep */
+ * coef: [T][5] = 1/sqrt(acp_t), sqrt(1-acp_t), c_x0, c_xt, sigma_t (0 at t = 0); t: device pointer to the (single) timestep;
+ * clip: bit 0 = clip_sample (predicted x0 clamped to [-1, 1]), bit 1 = the model output is the velocity (v-prediction) */
 int mi_ddpm_step(float* x, const void* eps, const float* noise, const float* coef, const int64_t* t, void* x_cl, int N, int C, int64_t V,
                  int clip, hipStream_t stream);
 int mi_mse_fwd_bwd(const void* pred, const float* target, void* dpred, float* loss, int N, int C, int64_t V, float grad_scale,

@@ -29,8 +29,8 @@ class DDPMScheduler:
                  prediction_type="epsilon", beta_start=1e-4, beta_end=2e-2):
         if variance_type != "fixed_small":
             raise NotImplementedError("only variance_type='fixed_small' (the upstream default the reference uses)")
-        if prediction_type != "epsilon":
-            raise NotImplementedError("only epsilon-prediction is on the HIP path (the reference's default, CFG:1012-1013)")
+        if prediction_type not in ("epsilon", "v_prediction"):
+            raise ValueError(f"unknown prediction_type {prediction_type}")
         if schedule == "scaled_linear_beta":
             betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=F32) ** 2
         elif schedule == "linear_beta":
@@ -75,7 +75,10 @@ class DDPMScheduler:
         below does not go through this (tensor-level) method."""
         t = int(timestep)
         k = self._coef[t].to(sample.device)
-        x0 = (sample - k[1] * model_output) * k[0]
+        if self.prediction_type == "v_prediction":
+            x0 = sample / k[0] - k[1] * model_output
+        else:
+            x0 = (sample - k[1] * model_output) * k[0]
         if self.clip_sample:
             x0 = x0.clamp(-1, 1)
         prev = k[2] * x0 + k[3] * sample
@@ -110,7 +113,7 @@ class _Loop:
         ctx = E.Ctx(self.arena, self.m._plans, grad_enabled=False, prepacked=self.keys)
         eps = self.m._run(ctx, self.x_cl, self.tn, need_dx=False)
         call("mi_ddpm_step", ptr(self.x), ptr(eps), ptr(self.z), ptr(self.coef), ptr(self.t), ptr(self.x_cl), self.n, self.c, self.v,
-             int(self.sch.clip_sample))
+             int(self.sch.clip_sample) | (2 if self.sch.prediction_type == "v_prediction" else 0))
 
     def run(self, input_noise, noises=None, generator=None, use_graph=True, on_step=None):
         self.x.copy_(input_noise)

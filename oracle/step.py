@@ -59,7 +59,10 @@ class DDPMSchedule:
     def step(self, model_output, timestep: int, sample, noise, clip_sample: bool = True):
         """x_{t-1} and the predicted x_0 (epsilon prediction), noise = the z of this step."""
         k = self.step_coefficients()[timestep]
-        x0 = (sample - k[1] * model_output) * k[0]
+        if self.prediction_type == "v_prediction":
+            x0 = sample / k[0] - k[1] * model_output
+        else:
+            x0 = (sample - k[1] * model_output) * k[0]
         if clip_sample:
             x0 = x0.clamp(-1, 1)
         prev = k[2] * x0 + k[3] * sample

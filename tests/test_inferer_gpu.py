@@ -29,6 +29,16 @@ def test_ddpm_step_kernel_matches_closed_form():
         call("mi_ddpm_step", ptr(xd), ptr(eps_cl), ptr(zd), ptr(sch.coefficients("cuda")), ptr(td), ptr(x_cl), shape[0], shape[1], 4 * 6 * 5, 1)
         assert float((xd.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
         assert float((ops.to_channels_first(x_cl).cpu() - want).abs().max()) <= 1e-2 * float(want.abs().max())
+    # v-prediction: the model output is the velocity
+    schv = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205, prediction_type="v_prediction")
+    refv = step.DDPMSchedule(prediction_type="v_prediction")
+    want, _ = refv.step(eps, 500, x, z, clip_sample=True)
+    xd, td = x.cuda(), torch.tensor([500], device="cuda")
+    call("mi_ddpm_step", ptr(xd), ptr(eps_cl), ptr(zd), ptr(schv.coefficients("cuda")), ptr(td), None, shape[0], shape[1], 4 * 6 * 5, 3)
+    assert float((xd.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    pv, _ = schv.step(eps, 0, x)
+    wv, _ = refv.step(eps, 0, x, None)
+    assert torch.allclose(pv, wv, atol=1e-5)
     # upstream's tensor-level step() signature
     prev, x0 = sch.step(eps, 0, x)
     w_prev, w_x0 = ref.step(eps, 0, x, None)
