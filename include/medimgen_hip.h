@@ -138,6 +138,10 @@ int mi_attn_bwd(const void* qkv, int ld, int C, int heads, int B, int S, float s
 
 /* ---- get_timestep_embedding (UNet:461-485), nn.SiLU on the embedding vector (UNet:1833, 692) --------------------------- */
 int mi_timestep_embedding(const int64_t* timesteps, float* out, int B, int dim, float max_period, hipStream_t stream);
+/* class embedding (nn.Embedding(num_class_embeds, 4*C0) added to the time embedding, UNet:1837-1839, 1975-1980):
+ * emb[b] += weight[labels[b]];  backward: dweight[labels[b]] += d_emb[b] (fp32, accumulated; labels must be < num_class_embeds) */
+int mi_embedding_add(float* emb, const float* weight, const int64_t* labels, int B, int dim, hipStream_t stream);
+int mi_embedding_bwd(const float* d_emb, const int64_t* labels, float* dweight, int B, int dim, hipStream_t stream);
 int mi_silu_f32(const float* x, float* y, int64_t n, hipStream_t stream);
 int mi_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, hipStream_t stream);
 

@@ -63,6 +63,8 @@ _SIGS = {
     "mi_silu_bwd_f32": [_p, _p, _p, _l, _p],
     "mi_logvar_to_sigma_fwd": [_p, _p, _l, _p],
     "mi_logvar_to_sigma_bwd": [_p, _p, _p, _p, _l, _p],
+    "mi_embedding_add": [_p, _p, _p, _i, _i, _p],
+    "mi_embedding_bwd": [_p, _p, _p, _i, _i, _p],
     "mi_qsample": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p],
     "mi_ddpm_step": [_p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
     "mi_mse_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _f, _p],

@@ -244,6 +244,21 @@ __global__ void k_reparam_kl_bwd(const bf16* __restrict__ mu, const bf16* __rest
   }
 }
 
+// ---------------------------------------------------------------- class embedding (nn.Embedding rows added to the time embedding,
+// UNet:1837-1839, 1975-1980): emb[b][:] += W[labels[b]][:];  backward: dW[labels[b]][:] += d_emb[b][:] (labels may repeat: atomics)
+__global__ void k_embedding_add(float* __restrict__ emb, const float* __restrict__ w, const int64_t* __restrict__ labels, int B, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * dim) return;
+  const int b = i / dim, j = i - b * dim;
+  emb[i] += w[labels[b] * dim + j];
+}
+__global__ void k_embedding_bwd(const float* __restrict__ d_emb, const int64_t* __restrict__ labels, float* __restrict__ dw, int B, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * dim) return;
+  const int b = i / dim, j = i - b * dim;
+  atomicAdd(dw + labels[b] * dim + j, d_emb[i]);
+}
+
 // ---------------------------------------------------------------- sinusoidal timestep embedding (UNet:461-485)
 __global__ void k_timestep_embedding(const int64_t* __restrict__ t, float* __restrict__ out, int B, int dim, float neg_log_period) {
   int half = dim / 2;
@@ -494,6 +509,18 @@ int mi_reparam_kl_bwd(const void* mu, const void* sigma, const float* eps, const
   if (total <= 0 || C <= 0) return MI_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_reparam_kl_bwd, dim3(grid_for(total, 1024)), dim3(kThreads), 0, st, (const bf16*)mu, (const bf16*)sigma, eps,
                      (const bf16*)dz, (bf16*)dmu, (bf16*)dsigma, C, V, total, kl_weight / (float)N);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_embedding_add(float* emb, const float* weight, const int64_t* labels, int B, int dim, hipStream_t st) {
+  if (B <= 0 || dim <= 0 || !emb || !weight || !labels) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_embedding_add, dim3(ceil_div((int64_t)B * dim, 256)), dim3(256), 0, st, emb, weight, labels, B, dim);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_embedding_bwd(const float* d_emb, const int64_t* labels, float* dweight, int B, int dim, hipStream_t st) {
+  if (B <= 0 || dim <= 0 || !d_emb || !dweight || !labels) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_embedding_bwd, dim3(ceil_div((int64_t)B * dim, 256)), dim3(256), 0, st, d_emb, labels, dweight, B, dim);
   MI_CHECK_LAUNCH();
   return 0;
 }

@@ -128,15 +128,16 @@ class _ArenaTrainer:
 
 
 class DDPMTrainer(_ArenaTrainer):
-    """step(x0, noise, timesteps): x0/noise fp32 NCDHW, timesteps int64 [N]."""
+    """step(x0, noise, timesteps[, class_labels]): x0/noise fp32 NCDHW, timesteps (and class_labels) int64 [N]."""
 
     def __init__(self, model, lr=2e-5, optimizer="AdamW", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  schedule: DDPMSchedule | None = None, process_group=None, bucket_mb=64, device=None):
         super().__init__(model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device)
         self.schedule = schedule or DDPMSchedule(device=self.device)
 
-    def forward_backward(self, x0, noise, timesteps):
-        """q-sample -> UNet -> MSE -> backward into the gradient arena.  x0/noise: fp32 NCDHW, timesteps: int64 [N]."""
+    def forward_backward(self, x0, noise, timesteps, class_labels=None):
+        """q-sample -> UNet -> MSE -> backward into the gradient arena.  x0/noise: fp32 NCDHW, timesteps: int64 [N];
+        class_labels: int64 [N], only for a net built with num_class_embeds."""
         m = self.model
         a = self.arena
         a.grad.zero_()
@@ -153,7 +154,9 @@ class DDPMTrainer(_ArenaTrainer):
         call("mi_qsample", ptr(x0), ptr(noise), ptr(self.schedule.sqrt_acp), ptr(self.schedule.sqrt_1macp), ptr(timesteps), ptr(x_t),
              ptr(target) if vpred else None, n, c, v)
         ctx = E.Ctx(a, m._plans, grad_enabled=True, prepacked=m.pack_all())
-        pred = m._run(ctx, x_t, timesteps, need_dx=False)
+        if (class_labels is None) != (getattr(m, "num_class_embeds", None) is None):
+            raise ValueError("class_labels should be provided exactly when the model has num_class_embeds")
+        pred = m._run(ctx, x_t, timesteps, need_dx=False, class_labels=class_labels)
         dpred = torch.empty_like(pred)
         call("mi_mse_fwd_bwd", ptr(pred), ptr(target), ptr(dpred), ptr(self.loss), n, pred.shape[-1], v, 1.0)
         ctx.tape.backward(pred, dpred)

@@ -18,6 +18,7 @@ from torch import nn
 
 from . import engine as E
 from . import hipops as ops
+from ._lib import call, ptr
 
 F32 = torch.float32
 
@@ -232,8 +233,8 @@ class DiffusionModelUNet(HipModule):
                              "`num_channels`.")
         if use_flash_attention:
             raise ValueError("use_flash_attention is True but xformers is not installed.")
-        if with_conditioning or num_class_embeds is not None or resblock_updown:
-            raise NotImplementedError("cross-attention / class-embedding / resblock_updown are not on the HIP path yet "
+        if with_conditioning or resblock_updown:
+            raise NotImplementedError("cross-attention / resblock_updown are not on the HIP path yet "
                                       "(never enabled by the reference's configs; SURVEY 8f-4)")
         if spatial_dims not in (2, 3):
             raise ValueError("spatial_dims must be 2 or 3")
@@ -245,6 +246,7 @@ class DiffusionModelUNet(HipModule):
         self.attention_levels = att = tuple(attention_levels)
         self.num_head_channels = nhc = tuple(num_head_channels)
         self.with_conditioning = False
+        self.num_class_embeds = num_class_embeds
         self.groups, self.eps = norm_num_groups, norm_eps
         L = len(ch)
         self._k = [_axis3(kernel_sizes[i], sd, 1) for i in range(L)]
@@ -300,6 +302,8 @@ class DiffusionModelUNet(HipModule):
                 spec.conv(f"up_blocks.{i}.upsampler.conv.conv", out_c, out_c, 3)
         spec.norm("out.0", ch[0])
         spec.conv("out.2.conv", ch[0], out_channels, 3, zero=True)
+        if num_class_embeds is not None:  # nn.Embedding(num_class_embeds, time_embed_dim): N(0, 1) rows (UNet:1837-1839)
+            spec._add("class_embedding.weight", torch.randn(num_class_embeds, temb))
 
         # arena adjacency: one GEMM for every time_emb_proj, one [3C, C] matrix per attention block
         groups = [[r[0] + ".time_emb_proj.weight" for r in self._resnets], [r[0] + ".time_emb_proj.bias" for r in self._resnets],
@@ -335,7 +339,7 @@ class DiffusionModelUNet(HipModule):
     def _heads(self, ch, nhc):
         return ch // nhc if nhc is not None else 1
 
-    def _run(self, c: E.Ctx, x_cl, timesteps, need_dx):
+    def _run(self, c: E.Ctx, x_cl, timesteps, need_dx, class_labels=None):
         ch, L, sd = self.block_out_channels, len(self.block_out_channels), self.spatial_dims
         a = c.arena
         dev = x_cl.device
@@ -345,6 +349,8 @@ class DiffusionModelUNet(HipModule):
         e1, bwd1 = E.linear_f32(t0, c.p("time_embed.0.weight"), c.p("time_embed.0.bias"), c.g("time_embed.0.weight"), c.g("time_embed.0.bias"))
         s1v = ops.silu_f32(e1)
         emb, bwd2 = E.linear_f32(s1v, c.p("time_embed.2.weight"), c.p("time_embed.2.bias"), c.g("time_embed.2.weight"), c.g("time_embed.2.bias"))
+        if self.num_class_embeds is not None:  # emb = emb + class_embedding(class_labels)  (UNet:1975-1980)
+            call("mi_embedding_add", ptr(emb), ptr(c.p("class_embedding.weight")), ptr(class_labels), emb.shape[0], emb.shape[1])
         se = ops.silu_f32(emb)
         wn = [r[0] + ".time_emb_proj.weight" for r in self._resnets]
         bn = [r[0] + ".time_emb_proj.bias" for r in self._resnets]
@@ -359,6 +365,8 @@ class DiffusionModelUNet(HipModule):
                 ops.sum_rows_f32(d_temb_all, a.span([r[0] + ".conv1.conv.bias" for r in self._resnets], a.grad), accumulate=True)
                 d_se = bwd3(d_temb_all)
                 d_emb = ops.silu_bwd_f32(emb, d_se)
+                if self.num_class_embeds is not None:
+                    call("mi_embedding_bwd", ptr(d_emb), ptr(class_labels), ptr(c.g("class_embedding.weight")), d_emb.shape[0], d_emb.shape[1])
                 d_s1 = bwd2(d_emb)
                 bwd1(ops.silu_bwd_f32(e1, d_s1), need_dx=False)
 
@@ -421,10 +429,16 @@ class DiffusionModelUNet(HipModule):
             raise RuntimeError("medical_image_generation_amd runs on MI355X only: move the module and inputs to 'cuda' "
                                "(there is no CPU fallback; the CPU restatement lives in oracle/ for tests)")
         timesteps = timesteps.to(device=x.device, dtype=torch.int64)
+        if self.num_class_embeds is not None:
+            if class_labels is None:
+                raise ValueError("class_labels should be provided when num_class_embeds > 0")
+            class_labels = class_labels.to(device=x.device, dtype=torch.int64).contiguous()
+            if class_labels.shape != timesteps.shape or int(class_labels.min()) < 0 or int(class_labels.max()) >= self.num_class_embeds:
+                raise IndexError("class_labels must hold one index in [0, num_class_embeds) per sample")  # nn.Embedding's range check
 
         def runner(c, xin, need_dx):
             x_cl = ops.to_channels_last(xin.contiguous().float())
-            y = self._run(c, x_cl, timesteps, need_dx)
+            y = self._run(c, x_cl, timesteps, need_dx, class_labels)
             return (y,), {"x_cl": x_cl}
 
         grad_enabled = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))

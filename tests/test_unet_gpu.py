@@ -125,3 +125,38 @@ def test_batch_consistency_at_realistic_size():
     err = float((g2 - g1).norm() / g1.norm())
     print(f"\n[C4 @64^3] loss {l1:.6f} / {l2:.6f}, batch-2 vs batch-1 gradient rel-L2 {err:.3e}")
     assert err <= 1e-2  # same math; bf16 rounding of the halved output gradient and split-reduction order differ (measured 2.3e-3)
+
+
+def test_class_embedding_matches_oracle():
+    """num_class_embeds (UNet:1837-1839, 1975-1980): emb += class_embedding(class_labels); forward, input gradient and the embedding
+    table's gradient (repeated labels accumulate) against the CPU restatement."""
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    c = cases.UNET_CASES["unet3d"]
+    kw = dict(c["kwargs"], num_class_embeds=5)
+    ref = nets.DiffusionModelUNet(**kw)
+    sd = synth.state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, cases.SEED)
+    ref.load_state_dict(sd)
+    net = DiffusionModelUNet(**kw)
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in sd.items()}
+    net.load_state_dict(sd)
+    net = net.cuda()
+    x = synth.ellipsoid_volume(cases.SEED, "x", c["shape"])
+    t = torch.tensor(c["timesteps"])
+    labels = torch.tensor([3] * c["shape"][0])  # the same row for every sample: its gradient rows must accumulate
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr, t, class_labels=labels)
+    g = synth.tensor(cases.SEED, "gy", tuple(yr.shape))
+    yr.backward(g)
+    xd = x.cuda().requires_grad_(True)
+    y = net(xd, t.cuda(), class_labels=labels.cuda())
+    y.backward(g.cuda())
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    e_y, e_dx = rel(y.detach().cpu(), yr.detach()), rel(xd.grad.cpu(), xr.grad)
+    gw_ref = dict(ref.named_parameters())["class_embedding.weight"].grad
+    gw = dict(net.named_parameters())["class_embedding.weight"].grad.cpu()
+    e_w = rel(gw, gw_ref)
+    print(f"\n[class embedding] prediction {e_y:.3e}, dx {e_dx:.3e}, d(class_embedding) {e_w:.3e}")
+    assert e_y <= 3e-2 and e_dx <= 3e-2 and e_w <= 6e-2
+    assert float(gw[[0, 1, 2, 4]].abs().max()) == 0.0  # untouched rows
+    with pytest.raises(ValueError):
+        net(xd, t.cuda())
