@@ -1697,7 +1697,7 @@ int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
 }
 
 int mi_conv_fwd_stats_chunks(const mi_conv_plan* P) {
-  if (!P || !P->v27_fwd || P->N > 16) return 0;
+  if (!P || !P->v27_fwd || P->N > 16 || P->ncb_fwd != 1) return 0;
   return 4 * mi_conv27_grid_x(P->N * P->g_fwd.tilesD * P->g_fwd.tilesH * P->g_fwd.tilesW, P->fwd.ny);
 }
 

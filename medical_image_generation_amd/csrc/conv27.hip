@@ -387,6 +387,9 @@ struct Epi {
   float sa[8], sq[8];       // a.stats: running sum / sum of squares of this lane's channel octet over the tiles of image sn
   int sn;
 };
+// (Statistics are compiled into the NCB = 1 variant only.  Measured same box, same call: with the code in both variants the C4 step
+// takes 25.5 ms, 25.8 ms when it is compiled in but unused, 25.3 ms with it in neither variant or in NCB = 1 alone -- the NCB = 2
+// kernel, 256 VGPRs and ~9000 instructions, loses more to the extra code than the fused statistics save.)
 // Fold the lanes that share a channel octet (they sit PV apart) and store this wave's chunk of image e.sn; resets the sums.
 template <int NCB>
 __device__ __forceinline__ void stats_flush(Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane) {
@@ -425,7 +428,7 @@ __device__ __forceinline__ void stats_zero(const ConvArgs& a, int y, int hl, int
 }
 template <int NCB>
 __device__ __forceinline__ void stats_begin_tile(Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane) {
-  if (a.stats && e.sn != e.n) {  // wave-uniform
+  if (NCB == 1 && a.stats && e.sn != e.n) {  // wave-uniform
     if (e.sn >= 0) stats_flush<NCB>(e, a, y, hl, lane);
     e.sn = e.n;
   }
@@ -480,7 +483,7 @@ __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char
       for (int j = 0; j < 8; ++j) f.v[j] += rr.v[j];
       raw = pack8(f);
     }
-    if (a.stats) {  // statistics of the ROUNDED values: what the consumer's GroupNorm will read
+    if (NCB == 1 && a.stats) {  // statistics of the ROUNDED values: what the consumer's GroupNorm will read
       const F8 f = unpack8(raw);
       const float mk = inside ? 1.f : 0.f;
 #pragma unroll
@@ -550,7 +553,7 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
 #pragma unroll
   for (int j = 0; j < 8; ++j) e.sa[j] = e.sq[j] = 0.f;
   e.sn = -1;
-  if (a.stats) stats_zero<NCB>(a, y, hl, lane);
+  if (NCB == 1 && a.stats) stats_zero<NCB>(a, y, hl, lane);
   int cur = 0;
   while (true) {
     seq_next(q, a, tile_step, tile_last);
@@ -594,7 +597,7 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
     wait_vm<0>();
     epi_process<0, KK::PV, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
   }
-  if (a.stats && e.sn >= 0) stats_flush<NCB>(e, a, y, hl, lane);
+  if (NCB == 1 && a.stats && e.sn >= 0) stats_flush<NCB>(e, a, y, hl, lane);
   wait_vm<0>();
 }
 
@@ -606,7 +609,7 @@ __global__ void __launch_bounds__(512, 2) k_conv27(ConvArgs a) {
   int tile_last, tile_step;
   const int tile0 = first_tile(a.ntiles, tile_last, tile_step);
   if (tile0 >= tile_last) {  // whole workgroup, before any barrier
-    if (a.stats && wave >= 4) stats_zero<NCB>(a, y, wave - 4, lane);
+    if (NCB == 1 && a.stats && wave >= 4) stats_zero<NCB>(a, y, wave - 4, lane);
     return;
   }
   if (wave < 4) compute_role<NCB, FLIP>(a, lds, y, wave, lane, tile0, tile_step, tile_last);
