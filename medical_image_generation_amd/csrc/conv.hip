@@ -1530,8 +1530,8 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
     }
   }
   const bool geo27 = P->full27 && P->g_fwd.TD == 4 && P->g_fwd.TH == 8 && P->g_fwd.TW == 8;
-  P->v27_fwd = use27 && geo27 && (Cin % 8) == 0;
-  P->v27_dg = use27 && geo27 && (Cout % 8) == 0;
+  P->v27_fwd = use27 && geo27 && (Cin % 8) == 0 && (Cout % 8) == 0;  // whole channel octets on both sides (else: table-driven kernel)
+  P->v27_dg = use27 && geo27 && (Cout % 8) == 0 && (Cin % 8) == 0;
   {
     static const int use11 = env_int("MI_CONV1X1", 1);
     const bool k1 = P->KT == 1 && !P->strided;
@@ -1750,7 +1750,9 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
     const int64_t yb = (int64_t)P->N * P->Do * P->Ho * P->Wo * y_cs * 2;
     a.y_bytes = yb < (1ll << 32) ? (unsigned)yb : 0u;
     a.stats = out_stats; a.stats_chunks = out_stats ? mi_conv_fwd_stats_chunks(P) : 0;
-    return mi_launch_conv27(a, P->ncb_fwd, 0, ntiles, P->fwd.ny, st);
+    const int e27 = mi_launch_conv27(a, P->ncb_fwd, 0, ntiles, P->fwd.ny, st);
+    if (e27 != MI_ERR_UNSUPPORTED || out_stats) return e27;  // (odd output pitch / >= 4 GiB output: the table-driven kernel below)
+    a.stats = nullptr;
   }
   return launch_igemm_any(a, P->ncb_fwd, P->full27 ? 1 : 0, ntiles, P->fwd.ny, st);
 }
@@ -1792,7 +1794,8 @@ int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_c
     if (dy_cs & 7) return MI_ERR_UNSUPPORTED;
     const int64_t yb = (int64_t)P->N * a.Do * a.Ho * a.Wo * a.y_cs * 2;
     a.y_bytes = yb < (1ll << 32) ? (unsigned)yb : 0u;
-    return mi_launch_conv27(a, P->ncb_dg, 1, ntiles, P->dg.ny, st);
+    const int e27 = mi_launch_conv27(a, P->ncb_dg, 1, ntiles, P->dg.ny, st);
+    if (e27 != MI_ERR_UNSUPPORTED) return e27;
   }
   int e = launch_igemm_any(a, P->ncb_dg, P->full27 ? 2 : 0, ntiles, P->dg.ny, st);
   if (e) return e;

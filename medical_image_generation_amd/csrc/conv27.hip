@@ -466,7 +466,7 @@ __device__ __forceinline__ void epi_issue_res(Epi<NCB>& e, const ConvArgs& a, in
   }
 }
 template <int P0, int CNT, int NCB>
-__device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, bool has_res, bool vec_ok) {
+__device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, bool has_res) {
   using KK = K<NCB>;
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y, a.y_bytes);
 #pragma unroll
@@ -493,28 +493,21 @@ __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char
         e.sq[j] = fmaf(t, f.v[j], e.sq[j]);
       }
     }
-    if (vec_ok) {  // always issued (masked lanes get an out-of-range offset): the store count is part of the vmcnt bookkeeping
+    {  // always issued (masked lanes get an out-of-range offset): the store count is part of the vmcnt bookkeeping.  The host only
+       // sends whole channel octets with an 8-aligned pitch here (ragged outputs stay on the table-driven kernel): an element-wise
+       // store path in every piece of every slot is code this kernel pays for even when it never runs (see stats_flush).
       const unsigned off = inside ? (vox * (unsigned)a.y_cs + (unsigned)co) * 2u : 0xfffffff0u;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, raw), ry, (int)off, 0, 0);
-    } else {  // ragged channel counts (Cout = 1, ...): element-wise
-      const int od = e.d0 + hl, oh = e.h0 + (v >> 3), ow = e.w0 + (v & 7);
-      if ((od < a.Do) & (oh < a.Ho) & (ow < a.Wo)) {
-        F8 f = unpack8(raw);
-        bf16* yp = a.y + (int64_t)vox * a.y_cs + co;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (co + j < a.Cout) yp[j] = f2bf(f.v[j]);
-      }
     }
   }
 }
 // pieces of store slot J (1 .. NG-1)
 template <int J, int NCB>
-__device__ __forceinline__ void epi_slot(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, int j, bool has_res, bool vec_ok) {
+__device__ __forceinline__ void epi_slot(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, int j, bool has_res) {
   using KK = K<NCB>;
   if constexpr (J < KK::NG) {
-    if (j == J) epi_process<(J - 1) * KK::PPT, KK::PPT, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
-    else epi_slot<J + 1, NCB>(e, a, lds, y, hl, lane, j, has_res, vec_ok);
+    if (j == J) epi_process<(J - 1) * KK::PPT, KK::PPT, NCB>(e, a, lds, y, hl, lane, has_res);
+    else epi_slot<J + 1, NCB>(e, a, lds, y, hl, lane, j, has_res);
   }
 }
 
@@ -529,7 +522,6 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
     hp[k] = v < HALO_VOX ? (((p ^ (hh & 3)) << 24) | (hd << 16) | (hh << 8) | hw) : -1;
   }
   const bool has_res = a.res != nullptr;
-  const bool vec_ok = (a.y_cs & 7) == 0 && (a.Cout & 7) == 0 && a.y_bytes != 0;
   const bool resident = a.nchunks == 1 && KK::NG <= RD;  // the ring holds every group of the only chunk: load once
   int a_ch = 0, a_j = 0, slot = 0, issued = 0;
   auto issue_next_A = [&]() {
@@ -568,20 +560,20 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
     // ---- tops 1 .. NG-2
     for (int j = 1; j < KK::NG - 1; ++j) {
       if (j == 1) wait_vm<HPW>();                 // younger than group 2's weights: the halo quarter
-      else if (epi && vec_ok) wait_vm<KK::PPT>();  // ... the stores of slot j-1
+      else if (epi) wait_vm<KK::PPT>();  // ... the stores of slot j-1
       else wait_vm<0>();
       __builtin_amdgcn_s_barrier();
       issue_next_A();
-      if (epi) epi_slot<1, NCB>(e, a, lds, y, hl, lane, j, has_res, vec_ok);
+      if (epi) epi_slot<1, NCB>(e, a, lds, y, hl, lane, j, has_res);
     }
     // ---- top NG-1: the last store slot runs BEFORE the barrier (a single-chunk tile's compute waves overwrite the staging tile right
     // after it); the next image's halo and group NG's weights must have landed, the stores of the last two slots may fly
     if (epi) {
-      epi_process<(KK::NG - 2) * KK::PPT, KK::PPT, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
+      epi_process<(KK::NG - 2) * KK::PPT, KK::PPT, NCB>(e, a, lds, y, hl, lane, has_res);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done
       e.active = 0;
     }
-    if (epi && vec_ok) wait_vm<2 * KK::PPT>(); else wait_vm<0>();  // younger than group NG's weights: the stores of the last two slots
+    if (epi) wait_vm<2 * KK::PPT>(); else wait_vm<0>();  // younger than group NG's weights: the stores of the last two slots
     __builtin_amdgcn_s_barrier();
     issue_next_A();
     if (q.ch == a.nchunks - 1 && !(a.dbg & 1)) { e.active = 1; e.n = q.n; e.d0 = q.d0; e.h0 = q.h0; e.w0 = q.w0; }
@@ -595,7 +587,7 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
     stats_begin_tile<NCB>(e, a, y, hl, lane);
     epi_issue_res<NCB>(e, a, y, hl, lane, has_res);
     wait_vm<0>();
-    epi_process<0, KK::PV, NCB>(e, a, lds, y, hl, lane, has_res, vec_ok);
+    epi_process<0, KK::PV, NCB>(e, a, lds, y, hl, lane, has_res);
   }
   if (NCB == 1 && a.stats && e.sn >= 0) stats_flush<NCB>(e, a, y, hl, lane);
   wait_vm<0>();
@@ -653,6 +645,7 @@ int mi_conv27_grid_x(int ntiles, int ny) {
 
 int mi_launch_conv27(const ConvArgs& a, int NCB, int flip, int ntiles, int ny, hipStream_t st) {
   if (a.g.TD != 4 || a.g.TH != 8 || a.g.TW != 8 || (a.x_cs & 7) || (a.Cin & 7)) return MI_ERR_BAD_ARG;
+  if ((a.y_cs & 7) || (a.Cout & 7) || a.y_bytes == 0) return MI_ERR_UNSUPPORTED;  // whole 16-byte pieces only (the caller falls back)
   if (a.res && (a.res_bytes == 0 || (a.res_cs & 7))) return MI_ERR_UNSUPPORTED;  // (>= 4 GiB is not reachable with the x_bytes limit)
   if (NCB == 1) return flip ? launch27<1, 1>(a, ntiles, ny, st) : launch27<1, 0>(a, ntiles, ny, st);
   if (NCB == 2) return flip ? launch27<2, 1>(a, ntiles, ny, st) : launch27<2, 0>(a, ntiles, ny, st);
