@@ -426,9 +426,9 @@ __device__ __forceinline__ void stats_zero(const ConvArgs& a, int y, int hl, int
         if (c < a.Cout) *(float2*)(a.stats + (((int64_t)n * a.Cout + c) * a.stats_chunks + chunk) * 2) = make_float2(0.f, 0.f);
       }
 }
-template <int NCB>
+template <int NCB, bool ST>
 __device__ __forceinline__ void stats_begin_tile(Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane) {
-  if (NCB == 1 && a.stats && e.sn != e.n) {  // wave-uniform
+  if (ST && a.stats && e.sn != e.n) {  // wave-uniform
     if (e.sn >= 0) stats_flush<NCB>(e, a, y, hl, lane);
     e.sn = e.n;
   }
@@ -465,7 +465,7 @@ __device__ __forceinline__ void epi_issue_res(Epi<NCB>& e, const ConvArgs& a, in
     e.res[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0));
   }
 }
-template <int P0, int CNT, int NCB>
+template <int P0, int CNT, int NCB, bool ST>
 __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, bool has_res) {
   using KK = K<NCB>;
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.y, a.y_bytes);
@@ -483,7 +483,7 @@ __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char
       for (int j = 0; j < 8; ++j) f.v[j] += rr.v[j];
       raw = pack8(f);
     }
-    if (NCB == 1 && a.stats) {  // statistics of the ROUNDED values: what the consumer's GroupNorm will read
+    if (ST && a.stats) {  // statistics of the ROUNDED values: what the consumer's GroupNorm will read
       const F8 f = unpack8(raw);
       const float mk = inside ? 1.f : 0.f;
 #pragma unroll
@@ -502,16 +502,17 @@ __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char
   }
 }
 // pieces of store slot J (1 .. NG-1)
-template <int J, int NCB>
+template <int J, int NCB, bool ST>
 __device__ __forceinline__ void epi_slot(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, int j, bool has_res) {
   using KK = K<NCB>;
   if constexpr (J < KK::NG) {
-    if (j == J) epi_process<(J - 1) * KK::PPT, KK::PPT, NCB>(e, a, lds, y, hl, lane, has_res);
-    else epi_slot<J + 1, NCB>(e, a, lds, y, hl, lane, j, has_res);
+    if (j == J) epi_process<(J - 1) * KK::PPT, KK::PPT, NCB, ST>(e, a, lds, y, hl, lane, has_res);
+    else epi_slot<J + 1, NCB, ST>(e, a, lds, y, hl, lane, j, has_res);
   }
 }
 
-template <int NCB>
+// ST: this instantiation carries the output-statistics code (forward kernel of the 32-channel variant only: see stats_flush)
+template <int NCB, bool ST>
 __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y, int hl, int lane, int tile0, int tile_step, int tile_last) {
   using KK = K<NCB>;
   int hp[HPW];  // this lane's halo DMA pieces: (logical slot << 24) | (hd << 16) | (hh << 8) | hw, or -1
@@ -545,7 +546,7 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
 #pragma unroll
   for (int j = 0; j < 8; ++j) e.sa[j] = e.sq[j] = 0.f;
   e.sn = -1;
-  if (NCB == 1 && a.stats) stats_zero<NCB>(a, y, hl, lane);
+  if (ST && a.stats) stats_zero<NCB>(a, y, hl, lane);
   int cur = 0;
   while (true) {
     seq_next(q, a, tile_step, tile_last);
@@ -553,7 +554,7 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
     // ---- top 0
     wait_vm<0>();  // group 1's weights are this wave's youngest operation
     __builtin_amdgcn_s_barrier();
-    if (epi) stats_begin_tile<NCB>(e, a, y, hl, lane);
+    if (epi) stats_begin_tile<NCB, ST>(e, a, y, hl, lane);
     epi_issue_res<NCB>(e, a, y, hl, lane, epi && has_res);
     issue_next_A();
     issue_halo(a, lds, hp, hl, cur ^ 1, q.ntile >= 0, q.nn, q.nd0, q.nh0, q.nw0, q.nch * 32);
@@ -564,12 +565,12 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
       else wait_vm<0>();
       __builtin_amdgcn_s_barrier();
       issue_next_A();
-      if (epi) epi_slot<1, NCB>(e, a, lds, y, hl, lane, j, has_res);
+      if (epi) epi_slot<1, NCB, ST>(e, a, lds, y, hl, lane, j, has_res);
     }
     // ---- top NG-1: the last store slot runs BEFORE the barrier (a single-chunk tile's compute waves overwrite the staging tile right
     // after it); the next image's halo and group NG's weights must have landed, the stores of the last two slots may fly
     if (epi) {
-      epi_process<(KK::NG - 2) * KK::PPT, KK::PPT, NCB>(e, a, lds, y, hl, lane, has_res);
+      epi_process<(KK::NG - 2) * KK::PPT, KK::PPT, NCB, ST>(e, a, lds, y, hl, lane, has_res);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done
       e.active = 0;
     }
@@ -584,12 +585,12 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
   wait_vm<0>();
   __builtin_amdgcn_s_barrier();  // final: the last tile's staging is complete
   if (e.active) {
-    stats_begin_tile<NCB>(e, a, y, hl, lane);
+    stats_begin_tile<NCB, ST>(e, a, y, hl, lane);
     epi_issue_res<NCB>(e, a, y, hl, lane, has_res);
     wait_vm<0>();
-    epi_process<0, KK::PV, NCB>(e, a, lds, y, hl, lane, has_res);
+    epi_process<0, KK::PV, NCB, ST>(e, a, lds, y, hl, lane, has_res);
   }
-  if (NCB == 1 && a.stats && e.sn >= 0) stats_flush<NCB>(e, a, y, hl, lane);
+  if (ST && a.stats && e.sn >= 0) stats_flush<NCB>(e, a, y, hl, lane);
   wait_vm<0>();
 }
 
@@ -601,11 +602,11 @@ __global__ void __launch_bounds__(512, 2) k_conv27(ConvArgs a) {
   int tile_last, tile_step;
   const int tile0 = first_tile(a.ntiles, tile_last, tile_step);
   if (tile0 >= tile_last) {  // whole workgroup, before any barrier
-    if (NCB == 1 && a.stats && wave >= 4) stats_zero<NCB>(a, y, wave - 4, lane);
+    if (NCB == 1 && FLIP == 0 && a.stats && wave >= 4) stats_zero<NCB>(a, y, wave - 4, lane);
     return;
   }
   if (wave < 4) compute_role<NCB, FLIP>(a, lds, y, wave, lane, tile0, tile_step, tile_last);
-  else helper_role<NCB>(a, lds, y, wave - 4, lane, tile0, tile_step, tile_last);
+  else helper_role<NCB, NCB == 1 && FLIP == 0>(a, lds, y, wave - 4, lane, tile0, tile_step, tile_last);
 }
 
 template <int NCB, int FLIP>
