@@ -2,7 +2,9 @@
 
 One JSON line on rank 0 (contract in the task statement).  A "step" = noise -> q-sample -> UNet forward -> MSE ->
 backward -> (gradient all-reduce) -> clip_grad_norm_ -> AdamW on one synthetic batch already resident in HBM.
-  python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py [--gpus N --steps K --warmup W]
+N > 1: one rank per GPU over RCCL -- either started by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`
+(RANK / WORLD_SIZE in the environment) or, without a launcher, by bench.py itself as a child process.
 """
 from __future__ import annotations
 
@@ -32,10 +34,31 @@ def synthetic_volume(shape, seed, device):
     return (x * (sum(v ** 2 for v in grids) <= 0.9)).to(device)
 
 
-# HBM traffic per launch of the two conv kernels at 128^3, 32->32, from separate rocprofv3 --pmc passes (FETCH_SIZE doubled
-# as MI355X_MICROARCH.md prescribes for wide streaming reads on gfx950, WRITE_SIZE as read; KB -> bytes); summary under
-# profiles/r01d_pmc_traffic.md.  Only valid for that exact shape; other sizes report null.
-PMC_TRAFFIC_128 = {"wgrad": (2 * 163048.8 + 30208.0) * 1024, "fwd": (2 * 97700.2 + 131072.0) * 1024}
+def kernel_source_hash():
+    """sha256 over the conv kernel sources: ties a PMC measurement to the binary it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("conv.hip", "conv27.hip", "conv_common.h", "common.h"):
+        with open(os.path.join(ROOT, "medical_image_generation_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(kind, size):
+    """HBM bytes per launch of the roofline kernels from the PMC passes committed under profiles/ (tools/pmc_traffic.py: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of tools/pmc_conv.py, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
+    streaming reads on gfx950).  Only a measurement of THESE kernel sources at THIS shape counts: anything else reports null."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json"))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if d.get("source_hash") == kernel_source_hash() and d.get("size") == size and kind in d.get("hbm_bytes_per_launch", {}):
+            best = d["hbm_bytes_per_launch"][kind]
+    return best
 
 
 def kernel_roofline(kind, size, iters=20):
@@ -64,17 +87,20 @@ def kernel_roofline(kind, size, iters=20):
     flops = 2.0 * size ** 3 * 32 * 32 * 27
     name = {"fwd": "k_conv27<1,0>", "wgrad": "k_conv_wgrad2<true> (+ k_wgrad_reduce, ~5 us, inside the timed launch pair)"}[kind]
     return {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-            "frac": flops / sec / MFMA_PEAK_BF16, "traffic": PMC_TRAFFIC_128[kind] if size == 128 else None,
+            "frac": flops / sec / MFMA_PEAK_BF16, "traffic": pmc_traffic(kind, size),
             "kernel": f"{name}: k3 s1 32->32 @{size}^3", "avg_launch_us": sec * 1e6,
-            "algorithmic_bytes": 2.0 * size ** 3 * 32 * 2}  # fwd: read x + write y; wgrad: read x + read dy (bf16, 32 ch)
+            "algorithmic_bytes": 2.0 * size ** 3 * 32 * 2,  # fwd: read x + write y; wgrad: read x + read dy (bf16, 32 ch)
+            "hbm_GBps_algorithmic": 2.0 * size ** 3 * 32 * 2 / sec / 1e9}
 
 
-def cpu_baseline(size=96):
-    """The oracle (CPU restatement of the reference, fp32) timed on this host: one full train step of the SAME net on a
-    smaller crop (bounded to ~10-30 s).  Threads = this job's CPU share (16 per GPU on the pool), not the host's 256."""
+def cpu_baseline(size=128, timed=2):
+    """The oracle (CPU restatement of the reference, fp32) timed on this host on the SAME workload as the GPU line: full train steps
+    (q-sample, forward, MSE, backward, clip, AdamW) of the C4 U-Net on one size^3 volume, 1 warm-up + `timed` timed steps, median
+    (BASELINE.md section 3).  Threads = this job's CPU share (16 per GPU on the pool), not the host's 256.  About a minute."""
     from oracle import nets, step
     threads = min(16, os.cpu_count() or 1)
     torch.set_num_threads(threads)
+    torch.manual_seed(42)
     net = nets.DiffusionModelUNet(**C4)
     for n, p in net.named_parameters():  # un-zero the zero_module'd convs so the backward is not trivially sparse
         if float(p.detach().abs().max()) == 0:
@@ -82,11 +108,38 @@ def cpu_baseline(size=96):
     opt = torch.optim.AdamW(net.parameters(), lr=2e-5)
     sched = step.DDPMSchedule()
     x0 = torch.rand(1, 1, size, size, size)
-    t0 = time.perf_counter()
-    step.ddpm_train_step(net, opt, sched, x0, torch.randn_like(x0), torch.tensor([500]))
-    dt = time.perf_counter() - t0
+    times = []
+    for k in range(1 + timed):
+        t0 = time.perf_counter()
+        step.ddpm_train_step(net, opt, sched, x0, torch.randn_like(x0), torch.tensor([(137 * k + 500) % 1000]))
+        times.append(time.perf_counter() - t0)
+    dt = sorted(times[1:])[len(times[1:]) // 2] if timed > 1 else times[-1]
     return {"value": size ** 3 / dt, "unit": "voxels/s", "cores": threads, "kind": "port",
-            "sample": f"1 full train step (fwd+bwd+clip+AdamW) of the C4 U-Net on one {size}^3 crop, fp32, {dt:.1f} s"}
+            "sample": f"1 warm-up + {timed} timed full train steps (fwd+bwd+clip+AdamW) of the C4 U-Net on one {size}^3 volume (the GPU "
+                      f"line's workload), fp32; median {dt:.1f} s/step (warm-up {times[0]:.1f} s)"}
+
+
+def step_breakdown(tr, x0, noise, t):
+    """GPU milliseconds of ONE eager step by C-ABI entry point (HIP events around every library call on the launch stream): which
+    kernel families the step spends its time in, so the whole-step MFMA fraction is explained by the record itself."""
+    from medical_image_generation_amd import _lib
+    with _lib.profile_calls() as prof:
+        tr.step(x0, noise, t)
+    torch.cuda.synchronize()
+    by = prof.summary()
+    groups = {"conv k3 fwd": ("mi_conv_fwd",), "conv dgrad": ("mi_conv_dgrad",), "conv wgrad": ("mi_conv_wgrad",),
+              "groupnorm": ("mi_gn_",), "attention": ("mi_attn_", "mi_softmax_", "mi_linear_wgrad"), "gemm / transpose": ("mi_gemm_", "mi_transpose_"),
+              "weight pack": ("mi_conv_pack",), "optimizer": ("mi_adam", "mi_sumsq", "mi_axpy"),
+              "resample / copy / add": ("mi_upsample", "mi_space", "mi_depth", "mi_copy", "mi_add_bf16", "mi_avgpool")}
+    out, used = {}, set()
+    for gname, prefixes in groups.items():
+        ms = sum(v for k, v in by.items() if k.startswith(prefixes))
+        used |= {k for k in by if k.startswith(prefixes)}
+        if ms > 0:
+            out[gname] = round(ms, 3)
+    out["other"] = round(sum(v for k, v in by.items() if k not in used), 3)
+    out["sum"] = round(sum(by.values()), 3)
+    return out
 
 
 def main():
@@ -105,6 +158,17 @@ def main():
         torch.cuda.set_device(0)
         print(json.dumps({"roofline": kernel_roofline("wgrad", args.size), "roofline_fwd": kernel_roofline("fwd", args.size)}), flush=True)
         return
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one rank per GPU as a CHILD process (torch.distributed.run) before this
+        # process has touched the GPU, and hand its exit code on.  Never exec / re-exec from a process that has initialised HIP.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0)) % max(torch.cuda.device_count(), 1)
@@ -117,7 +181,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     from medical_image_generation_amd.trainer import DDPMTrainer
     from medical_image_generation_amd.unet import DiffusionModelUNet
@@ -199,6 +264,8 @@ def main():
             "roofline": roof,
             "roofline_fwd": roof_fwd,
         }
+        if world == 1:
+            out["step_breakdown_ms"] = step_breakdown(tr, x0, noise, t)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

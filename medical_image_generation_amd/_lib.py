@@ -52,8 +52,8 @@ _SIGS = {
     "mi_zero_f32_2d": [_p, _i, _i, _i, _p],
     "mi_gemm_nt_bf16": [_p, _i, _l, _l, _p, _i, _l, _l, _p, _i, _l, _l, _p, _p, _i, _l, _l, _i, _i, _i, _i, _i, _f, _i, _i, _p],
     "mi_transpose_bf16": [_p, _i, _l, _l, _p, _i, _l, _l, _i, _i, _i, _i, _p],
-    "mi_softmax_fwd": [_p, _p, _l, _i, _p],
-    "mi_softmax_bwd": [_p, _p, _p, _l, _i, _f, _p],
+    "mi_softmax_fwd": [_p, _p, _l, _i, _i, _p],
+    "mi_softmax_bwd": [_p, _p, _p, _l, _i, _i, _f, _p],
     "mi_attn_supported": [_i, _i],
     "mi_attn_workspace_bytes": [_i, _i, _i, _i],
     "mi_attn_fwd": [_p, _i, _i, _i, _i, _i, _f, _p, _p, _p, _p, _l, _p],
@@ -65,7 +65,9 @@ _SIGS = {
     "mi_logvar_to_sigma_bwd": [_p, _p, _p, _p, _l, _p],
     "mi_embedding_add": [_p, _p, _p, _i, _i, _p],
     "mi_embedding_bwd": [_p, _p, _p, _i, _i, _p],
-    "mi_qsample": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _p],
+    "mi_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "mi_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "mi_qsample": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
     "mi_ddpm_step": [_p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
     "mi_mse_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _f, _p],
     "mi_l1_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _i, _p],
@@ -73,7 +75,9 @@ _SIGS = {
     "mi_reparam_kl_bwd": [_p, _p, _p, _p, _p, _p, _i, _i, _l, _f, _p],
     "mi_sumsq_f32": [_p, _l, _p, _i, _p],
     "mi_clip_grad_by_norm": [_p, _l, _p, _f, _p],
-    "mi_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _p, _p],
+    "mi_adam_step": [_p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _i, _p, _f, _f, _p, _p],
+    "mi_axpy_f32": [_p, _p, _f, _l, _p],
+    "mi_scale_f32": [_p, _f, _l, _p],
 }
 _RET = {"mi_gn_workspace_bytes": _l, "mi_attn_workspace_bytes": _l}
 _NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes", "mi_attn_supported", "mi_attn_workspace_bytes", "mi_conv_fwd_stats_chunks"}
@@ -121,10 +125,44 @@ def ptr(t):
     return t.data_ptr()
 
 
+_profile = None
+
+
+class profile_calls:
+    """Context manager: HIP events on the launch stream around every library call made inside it (eager mode only -- events cannot
+    be recorded into a capturing stream this way); summary() -> {entry point: GPU milliseconds}.  Measurement aid for bench.py."""
+
+    def __enter__(self):
+        global _profile
+        self.records = []
+        _profile = self
+        return self
+
+    def __exit__(self, *exc):
+        global _profile
+        _profile = None
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.records:
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        return out
+
+
 def call(name: str, *args):
     """Invoke `name` on the current stream (appended as the last argument) and check the status."""
     fn = getattr(load(), name)
+    prof = _profile
+    if prof is not None:
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
     rc = fn(*args, stream_ptr())
+    if prof is not None:
+        e1.record(st)
+        prof.records.append((name, e0, e1))
     if rc != 0:
         raise HipError(f"{name} failed: {_ERRS.get(rc, f'hipError_t {rc}')}")
 

@@ -7,7 +7,9 @@ same methods (`forward`, `encode`, `sampling`, `decode`, `reconstruct`, `encode_
 one autograd edge over the HIP tape engine; `sampling` is the reference's own two-op reparameterisation on the (tiny)
 latent tensors.
 
-`use_checkpointing` is accepted and ignored: activations are kept (a 128^3 step needs < 40 GB of 288 GB).
+`use_checkpointing=True` checkpoints the whole encoder and the whole decoder, like the reference's torch.utils.checkpoint calls
+(AEKL:761-762, 815-816): their activations are dropped after the forward and recomputed inside the backward (engine.checkpoint;
+gradients bit-identical to the stored-activation path).
 `use_convtranspose=True` raises NotImplementedError (never set by the reference's planner, CFG:843).
 """
 from __future__ import annotations
@@ -151,6 +153,11 @@ class AutoencoderKL(HipModule):
 
     # ------------------------------------------------------------------------------------------ engine
     def _run_plan(self, c: E.Ctx, plan, x, need_dx):
+        if self.use_checkpointing and c.tape is not None:  # h = torch.utils.checkpoint.checkpoint(self.encoder | self.decoder, x)
+            return E.checkpoint(c, lambda cc, xx: self._run_plan_body(cc, plan, xx, need_dx), x)
+        return self._run_plan_body(c, plan, x, need_dx)
+
+    def _run_plan_body(self, c: E.Ctx, plan, x, need_dx):
         pending_norm = None
         first = True
         for step in plan:
@@ -211,7 +218,7 @@ class AutoencoderKL(HipModule):
 
     def _edge(self, runner, nouts, x):
         grad_enabled = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        return _NetFn.apply(self, runner, nouts, grad_enabled, x, *self.parameters())
+        return _NetFn.apply(self, runner, nouts, grad_enabled, x, None, *self.parameters())
 
     def encode(self, x):
         self._check(x, self.in_channels)

@@ -106,6 +106,66 @@ __global__ void k_upsample_bwd(const bf16* __restrict__ dy, bf16* __restrict__ d
   }
 }
 
+// ---------------------------------------------------------------- average pooling (nn.AvgPool{2,3}d(kernel, stride), no padding, floor mode)
+// ResnetBlock(down=True) resamples with Pool[AVG](kernel_size, stride) (UNet:522, 640-644, 679-687).
+// fwd: y[n, od, oh, ow, :] = mean over the kd*kh*kw window starting at (od*sd, oh*sh, ow*sw)
+__global__ void k_avgpool_fwd(const bf16* __restrict__ x, bf16* __restrict__ y, int D, int H, int W, int C8, int kd, int kh, int kw, int sd,
+                              int sh, int sw, int Do, int Ho, int Wo, int64_t total) {
+  const float inv = 1.0f / (float)(kd * kh * kw);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C8);
+    int64_t t = i / C8;
+    int w = (int)(t % Wo); t /= Wo;
+    int h = (int)(t % Ho); t /= Ho;
+    int d = (int)(t % Do);
+    int64_t n = t / Do;
+    F8 acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+    for (int a = 0; a < kd; ++a)
+      for (int b = 0; b < kh; ++b)
+        for (int e = 0; e < kw; ++e) {
+          int64_t src = (((n * D + d * sd + a) * H + h * sh + b) * W + w * sw + e) * C8 + c;
+          F8 g = unpack8(((const u32x4*)x)[src]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc.v[j] += g.v[j];
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] *= inv;
+    ((u32x4*)y)[i] = pack8(acc);
+  }
+}
+// bwd (gather form, windows may overlap or leave gaps): dx[n, d, h, w, :] = sum over the windows that contain (d, h, w) of dy / volume
+__global__ void k_avgpool_bwd(const bf16* __restrict__ dy, bf16* __restrict__ dx, int D, int H, int W, int C8, int kd, int kh, int kw, int sd,
+                              int sh, int sw, int Do, int Ho, int Wo, int64_t total) {
+  const float inv = 1.0f / (float)(kd * kh * kw);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C8);
+    int64_t t = i / C8;
+    int w = (int)(t % W); t /= W;
+    int h = (int)(t % H); t /= H;
+    int d = (int)(t % D);
+    int64_t n = t / D;
+    // outputs o with o*s <= i <= o*s + k - 1
+    int d0 = max(0, (d - kd + sd) / sd), d1 = min(Do - 1, d / sd);
+    int h0 = max(0, (h - kh + sh) / sh), h1 = min(Ho - 1, h / sh);
+    int w0 = max(0, (w - kw + sw) / sw), w1 = min(Wo - 1, w / sw);
+    F8 acc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] = 0.f;
+    for (int a = d0; a <= d1; ++a)
+      for (int b = h0; b <= h1; ++b)
+        for (int e = w0; e <= w1; ++e) {
+          F8 g = unpack8(((const u32x4*)dy)[(((n * Do + a) * Ho + b) * Wo + e) * C8 + c]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc.v[j] += g.v[j];
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc.v[j] *= inv;
+    ((u32x4*)dx)[i] = pack8(acc);
+  }
+}
+
 // ---------------------------------------------------------------- space <-> depth (per-axis factor 1 or 2)
 // s2d: out[n, d', h', w', q*C + c] = in[n, d'*fd + qd, h'*fh + qh, w'*fw + qw, c], q = (qd*fh + qh)*fw + qw
 // (positions beyond the input extent read as zero: odd sizes).  d2s is the inverse scatter.
@@ -139,10 +199,12 @@ __global__ void k_space_depth(const bf16* __restrict__ in, bf16* __restrict__ ou
 // velocity (optional, fp32 NCDHW): the v-prediction target a * noise - b * x0 (scheduler.get_velocity, T-LDM:163-165)
 __global__ void k_qsample(const float* __restrict__ x0, const float* __restrict__ noise, const float* __restrict__ sqrt_acp,
                           const float* __restrict__ sqrt_1macp, const int64_t* __restrict__ t, bf16* __restrict__ out,
-                          float* __restrict__ velocity, int C, int64_t V, int64_t total) {
+                          float* __restrict__ velocity, int C, int64_t V, int64_t total, int T) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t n = i / V, v = i - n * V;
-    float a = sqrt_acp[t[n]], b = sqrt_1macp[t[n]];
+    int64_t tn = t[n];
+    tn = tn < 0 ? 0 : (tn >= T ? T - 1 : tn);  // an out-of-range timestep must not index past the schedule tables
+    float a = sqrt_acp[tn], b = sqrt_1macp[tn];
     for (int c = 0; c < C; ++c) {
       int64_t s = (n * C + c) * V + v;
       const float xv = x0[s], nv = noise[s];
@@ -180,15 +242,16 @@ __global__ void k_ddpm_step(float* __restrict__ x, const bf16* __restrict__ eps,
 // loss = mean((pred - target)^2) over all elements; dpred = 2 (pred - target) / numel * loss_scale.
 // pred NDHWC bf16, target NCDHW fp32, dpred NDHWC bf16.  loss accumulated with one atomic per block into *loss_sum.
 __global__ void k_mse(const bf16* __restrict__ pred, const float* __restrict__ target, bf16* __restrict__ dpred,
-                      float* __restrict__ loss_sum, int C, int64_t V, int64_t total, float inv_numel) {
+                      float* __restrict__ loss_sum, int C, int64_t V, int64_t total, float inv_numel, float grad_scale) {
   __shared__ float red[4];
   float acc = 0.f;
+  const float gs = 2.f * inv_numel * grad_scale;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t n = i / V, v = i - n * V;
     for (int c = 0; c < C; ++c) {
       float d = bf2f(pred[i * C + c]) - target[(n * C + c) * V + v];
       acc += d * d;
-      if (dpred) dpred[i * C + c] = f2bf(2.f * d * inv_numel);
+      if (dpred) dpred[i * C + c] = f2bf(d * gs);
     }
   }
   float s = block_sum_256(acc, red);
@@ -452,12 +515,38 @@ int mi_depth_to_space(const void* in, void* out, int N, int D, int H, int W, int
   MI_CHECK_LAUNCH();
   return 0;
 }
+static int avgpool_dims(int D, int H, int W, const int k[3], const int s[3], int o[3]) {
+  const int in[3] = {D, H, W};
+  for (int a = 0; a < 3; ++a) {
+    if (k[a] <= 0 || s[a] <= 0 || in[a] < k[a]) return MI_ERR_BAD_ARG;
+    o[a] = (in[a] - k[a]) / s[a] + 1;
+  }
+  return 0;
+}
+int mi_avgpool_fwd(const void* x, void* y, int N, int D, int H, int W, int C, const int kernel[3], const int stride[3], hipStream_t st) {
+  int o[3];
+  if (!x || !y || N <= 0 || C <= 0 || (C & 7) || avgpool_dims(D, H, W, kernel, stride, o)) return MI_ERR_BAD_ARG;
+  int64_t total = (int64_t)N * o[0] * o[1] * o[2] * (C / 8);
+  hipLaunchKernelGGL(k_avgpool_fwd, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)x, (bf16*)y, D, H, W, C / 8, kernel[0], kernel[1],
+                     kernel[2], stride[0], stride[1], stride[2], o[0], o[1], o[2], total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_avgpool_bwd(const void* dy, void* dx, int N, int D, int H, int W, int C, const int kernel[3], const int stride[3], hipStream_t st) {
+  int o[3];
+  if (!dy || !dx || N <= 0 || C <= 0 || (C & 7) || avgpool_dims(D, H, W, kernel, stride, o)) return MI_ERR_BAD_ARG;
+  int64_t total = (int64_t)N * D * H * W * (C / 8);
+  hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)dy, (bf16*)dx, D, H, W, C / 8, kernel[0], kernel[1],
+                     kernel[2], stride[0], stride[1], stride[2], o[0], o[1], o[2], total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
 int mi_qsample(const float* x0, const float* noise, const float* sqrt_acp, const float* sqrt_1macp, const int64_t* t, void* out,
-               float* velocity, int N, int C, int64_t V, hipStream_t st) {
+               float* velocity, int N, int C, int64_t V, int num_train_timesteps, hipStream_t st) {
   int64_t total = (int64_t)N * V;
-  if (total <= 0) return MI_ERR_BAD_ARG;
+  if (total <= 0 || num_train_timesteps <= 0 || !x0 || !noise || !sqrt_acp || !sqrt_1macp || !t || !out) return MI_ERR_BAD_ARG;
   hipLaunchKernelGGL(k_qsample, dim3(grid_for(total)), dim3(kThreads), 0, st, x0, noise, sqrt_acp, sqrt_1macp, t, (bf16*)out, velocity, C, V,
-                     total);
+                     total, num_train_timesteps);
   MI_CHECK_LAUNCH();
   return 0;
 }
@@ -476,9 +565,8 @@ int mi_mse_fwd_bwd(const void* pred, const float* target, void* dpred, float* lo
   if (total <= 0) return MI_ERR_BAD_ARG;
   hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
   if (e != hipSuccess) return (int)e;
-  (void)grad_scale;
   hipLaunchKernelGGL(k_mse, dim3(grid_for(total, 1024)), dim3(kThreads), 0, st, (const bf16*)pred, target, (bf16*)dpred, loss, C, V, total,
-                     1.0f / (float)(total * C));
+                     1.0f / (float)(total * C), grad_scale);
   MI_CHECK_LAUNCH();
   return 0;
 }

@@ -127,6 +127,8 @@ __global__ void __launch_bounds__(256) k_gemm_nt(GemmArgs p) {
 }
 
 // ------------------------------------------------------------------ batched 2-D transpose (bf16), 64x64 tiles
+// Output rows are zero-filled from column R up to the next multiple of 8 that fits the pitch (R itself becomes the K axis of a GEMM,
+// whose 16-byte operand loads need K % 8 == 0: ragged token counts such as 3^3 = 27).
 __global__ void __launch_bounds__(256) k_transpose(const bf16* __restrict__ in, bf16* __restrict__ out, int R, int Cc, int ld_in,
                                                    int ld_out, int Z2, int64_t si1, int64_t si2, int64_t so1, int64_t so2) {
   __shared__ bf16 t[64][66];
@@ -142,14 +144,16 @@ __global__ void __launch_bounds__(256) k_transpose(const bf16* __restrict__ in, 
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     int cc = i >> 6, rr = i & 63;
     if (c0 + cc < Cc && r0 + rr < R) out[(int64_t)(c0 + cc) * ld_out + r0 + rr] = t[rr][cc];
+    else if (c0 + cc < Cc && r0 + rr < min((R + 7) & ~7, ld_out)) out[(int64_t)(c0 + cc) * ld_out + r0 + rr] = f2bf(0.f);
   }
 }
 
 // ------------------------------------------------------------------ row softmax: fp32 scores -> bf16 probabilities
-__global__ void __launch_bounds__(256) k_softmax_fwd(const float* __restrict__ s, bf16* __restrict__ pr, int cols) {
+// ldp: row pitch of the bf16 matrices (>= cols); columns [cols, ldp) are written as zeros (K padding of the products that follow)
+__global__ void __launch_bounds__(256) k_softmax_fwd(const float* __restrict__ s, bf16* __restrict__ pr, int cols, int ldp) {
   __shared__ float red[4];
   const float* row = s + (int64_t)blockIdx.x * cols;
-  bf16* o = pr + (int64_t)blockIdx.x * cols;
+  bf16* o = pr + (int64_t)blockIdx.x * ldp;
   float mx = -3.0e38f;
   for (int j = threadIdx.x; j < cols; j += 256) mx = fmaxf(mx, row[j]);
   mx = wave_max(mx);
@@ -161,18 +165,20 @@ __global__ void __launch_bounds__(256) k_softmax_fwd(const float* __restrict__ s
   sum = block_sum_256(sum, red);
   const float inv = 1.0f / sum;
   for (int j = threadIdx.x; j < cols; j += 256) o[j] = f2bf(__expf(row[j] - mx) * inv);
+  for (int j = cols + threadIdx.x; j < ldp; j += 256) o[j] = f2bf(0.f);
 }
 // dS = P * (dP - sum_k dP_k P_k) * scale
 __global__ void __launch_bounds__(256) k_softmax_bwd(const bf16* __restrict__ pr, const float* __restrict__ dp, bf16* __restrict__ ds,
-                                                     int cols, float scale) {
+                                                     int cols, int ldp, float scale) {
   __shared__ float red[4];
-  const bf16* prow = pr + (int64_t)blockIdx.x * cols;
+  const bf16* prow = pr + (int64_t)blockIdx.x * ldp;
   const float* drow = dp + (int64_t)blockIdx.x * cols;
-  bf16* o = ds + (int64_t)blockIdx.x * cols;
+  bf16* o = ds + (int64_t)blockIdx.x * ldp;
   float dot = 0.f;
   for (int j = threadIdx.x; j < cols; j += 256) dot += bf2f(prow[j]) * drow[j];
   dot = block_sum_256(dot, red);
   for (int j = threadIdx.x; j < cols; j += 256) o[j] = f2bf(bf2f(prow[j]) * (drow[j] - dot) * scale);
+  for (int j = cols + threadIdx.x; j < ldp; j += 256) o[j] = f2bf(0.f);
 }
 
 }  // namespace
@@ -208,15 +214,16 @@ int mi_transpose_bf16(const void* in, int ld_in, int64_t si1, int64_t si2, void*
   return 0;
 }
 
-int mi_softmax_fwd(const float* scores, void* probs, int64_t rows, int cols, hipStream_t st) {
-  if (rows <= 0 || cols <= 0 || rows > 2147483647LL) return MI_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_softmax_fwd, dim3((int)rows), dim3(256), 0, st, scores, (bf16*)probs, cols);
+int mi_softmax_fwd(const float* scores, void* probs, int64_t rows, int cols, int ld_probs, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || rows > 2147483647LL || ld_probs < cols) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_softmax_fwd, dim3((int)rows), dim3(256), 0, st, scores, (bf16*)probs, cols, ld_probs);
   MI_CHECK_LAUNCH();
   return 0;
 }
-int mi_softmax_bwd(const void* probs, const float* dprobs, void* dscores, int64_t rows, int cols, float scale, hipStream_t st) {
-  if (rows <= 0 || cols <= 0 || rows > 2147483647LL) return MI_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_softmax_bwd, dim3((int)rows), dim3(256), 0, st, (const bf16*)probs, dprobs, (bf16*)dscores, cols, scale);
+int mi_softmax_bwd(const void* probs, const float* dprobs, void* dscores, int64_t rows, int cols, int ld_probs, float scale,
+                   hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || rows > 2147483647LL || ld_probs < cols) return MI_ERR_BAD_ARG;
+  hipLaunchKernelGGL(k_softmax_bwd, dim3((int)rows), dim3(256), 0, st, (const bf16*)probs, dprobs, (bf16*)dscores, cols, ld_probs, scale);
   MI_CHECK_LAUNCH();
   return 0;
 }

@@ -11,6 +11,7 @@ Everything here launches HIP kernels through hipops; torch only allocates (torch
 from __future__ import annotations
 
 import math
+import weakref
 
 import torch
 
@@ -40,10 +41,14 @@ class ParamArena:
     tensors (`proj_attn.*`, never called: UNet:383 vs 418-458) sit behind it and are never updated -- the same
     outcome as torch.optim skipping parameters whose grad is None."""
 
-    def __init__(self, entries, device):
-        # entries: list of (name, shape, trainable)
+    def __init__(self, entries, device, late=()):
+        # entries: list of (name, shape, trainable); late: names of the trainable tensors whose gradients complete LAST in the
+        # backward pass (they must form a prefix of `entries`): [0, n_late) is that prefix, [n_late, n_trainable) the early segment
+        # whose data-parallel all-reduce may start at the backward's cut mark (trainer._ArenaTrainer)
         self.offsets, self.shapes = {}, {}
+        late = set(late)
         off = 0
+        self.n_late = 0
         for trainable_pass in (True, False):
             for name, shape, trainable in entries:
                 if trainable != trainable_pass:
@@ -53,6 +58,9 @@ class ParamArena:
                 off += n
                 if not trainable_pass or n % 4:
                     off = (off + 3) // 4 * 4
+                if trainable_pass and name in late:
+                    assert self.n_late == self.offsets[name], f"late tensors must form a prefix of the arena ({name})"
+                    self.n_late = off
             if trainable_pass:
                 off = (off + 3) // 4 * 4
                 self.n_trainable = off
@@ -80,6 +88,11 @@ class ParamArena:
 
 
 # --------------------------------------------------------------------------------------------- tape
+def CUT():
+    """Tape marker (a no-op when called): recorded by a model at the forward position behind which -- in backward order: before
+    which -- every gradient of the arena's early segment is final.  trainer._ArenaTrainer splits the backward there."""
+
+
 class Tape:
     def __init__(self):
         self.fns = []
@@ -115,10 +128,20 @@ class Ctx:
         # algorithmic matmul-class flops of this pass (2*MACs; torch.utils.flop_counter convention)
         self.flops_fwd = 0
         self.flops_bwd = 0
-        # id(tensor) -> (ChannelSums, tensor): per-channel sums the producing conv emitted, so that the GroupNorm consuming the
-        # tensor skips its statistics pass; id(concatenation) -> (a, b) lets a GroupNorm over a concat use both halves' sums
+        # id(tensor) -> (ChannelSums, weakref(tensor)): per-channel sums the producing conv emitted, so that the GroupNorm consuming
+        # the tensor skips its statistics pass; id(concatenation) -> (a, b, weakref(cat)) lets a GroupNorm over a concat use both
+        # halves' sums.  The keys are ids of tensors these dicts do NOT keep alive (a no-grad pass frees activations as it goes and
+        # CPython reuses ids), so every lookup checks that the weak reference still IS the tensor asked about.
         self.sums = {}
         self.cat_parts = {}
+
+    def sums_of(self, x):
+        ent = self.sums.get(id(x))
+        return ent[0] if ent is not None and ent[1]() is x else None
+
+    def parts_of(self, x):
+        ent = self.cat_parts.get(id(x))
+        return ent[:2] if ent is not None and ent[2]() is x else None
 
     def count(self, fwd_flops, dgrad=True, wgrad=True):
         self.flops_fwd += fwd_flops
@@ -166,13 +189,13 @@ def gn(ctx: Ctx, x, name, groups, eps):
     st = None
     if FUSE_GN_STATS:
         n, v = x.shape[0], x.shape[1] * x.shape[2] * x.shape[3]
-        ent, parts = ctx.sums.get(id(x)), ctx.cat_parts.get(id(x))
+        ent, parts = ctx.sums_of(x), ctx.parts_of(x)
         if ent is not None:
-            st = ops.gn_stats_from_sums(ent[0], None, n, v, groups, eps, gamma, beta)
+            st = ops.gn_stats_from_sums(ent, None, n, v, groups, eps, gamma, beta)
         elif parts is not None:
-            ea, eb = ctx.sums.get(id(parts[0])), ctx.sums.get(id(parts[1]))
+            ea, eb = ctx.sums_of(parts[0]), ctx.sums_of(parts[1])
             if ea is not None and eb is not None:
-                st = ops.gn_stats_from_sums(ea[0], eb[0], n, v, groups, eps, gamma, beta)
+                st = ops.gn_stats_from_sums(ea, eb, n, v, groups, eps, gamma, beta)
     if st is None:
         st = ops.gn_stats(x, groups, eps, gamma, beta)
     st.name = name
@@ -203,7 +226,7 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
         xin, pn, ps = x, norm, silu
     y, sums = plan.fwd(xin, pn, ps, addvec=av, res=res, out=out, want_sums=True)  # out: channel-slice view of the consumer's concat buffer
     if sums is not None:
-        ctx.sums[id(y)] = (sums, y)
+        ctx.sums[id(y)] = (sums, weakref.ref(y))
     ctx.count(2 * y.numel() * cin * math.prod(kernel), dgrad=need_dx)
     if ctx.tape is not None:
         tape = ctx.tape
@@ -246,10 +269,127 @@ def upsample(ctx: Ctx, x, factors):
         def bwd():
             dy = tape.take(y)
             if dy is not None:
-                tape.put(x, ops.upsample_nearest_bwd(dy, factors))
+                tape.put(x, ops.upsample_nearest_bwd(ops.dense(dy), factors))  # dy may be a slice view of d(concat)
 
         tape.record(bwd)
     return y
+
+
+def checkpoint(ctx: Ctx, fn, x):
+    """Activation checkpointing at tape level (the torch.utils.checkpoint of autoencoderkl_with_strides.py:761-762, 815-816, also
+    offered per block for the U-Net): y = fn(ctx', x) runs WITHOUT a tape, so every intermediate of the segment is freed as soon
+    as its consumer has run; the recorded backward re-runs fn with a tape and back-propagates through it.  The recomputation
+    launches the same kernels on the same inputs, and the segment input's pending gradient is handed to the inner tape so that
+    the fused "+ other branch" of the GroupNorm backward sees what it would have seen: gradients are bit-identical to the
+    stored-activation path (tests/test_checkpoint_gpu.py).  Recomputed flops are not counted (SURVEY 8d convention)."""
+    if ctx.tape is None:
+        return fn(ctx, x)
+    sub = Ctx(ctx.arena, ctx.plans, grad_enabled=False)
+    sub.packed, sub.sums, sub.cat_parts = ctx.packed, ctx.sums, ctx.cat_parts  # same packed weights, same emitted channel sums
+    y = fn(sub, x)
+    ctx.flops_fwd += sub.flops_fwd
+    ctx.flops_bwd += 2 * sub.flops_fwd
+    tape = ctx.tape
+
+    def bwd():
+        dy = tape.take(y)
+        if dy is None:
+            return
+        inner = Ctx(ctx.arena, ctx.plans, grad_enabled=True)
+        inner.packed, inner.sums, inner.cat_parts = ctx.packed, ctx.sums, ctx.cat_parts
+        y2 = fn(inner, x)
+        it = inner.tape
+        pending = tape.take(x)
+        if pending is not None:
+            it.grads[id(x)] = pending
+            it.keep.append(x)
+        it.backward(y2, dy)
+        g = it.take(x)
+        if g is not None:
+            tape.grads[id(x)] = g
+            tape.keep.append(x)
+        it.grads.clear(), it.keep.clear()
+
+    tape.record(bwd)
+    return y
+
+
+def avg_pool(ctx: Ctx, x, kernel, stride):
+    """Pool[AVG](kernel_size, stride) of Downsample(use_conv=False) (UNet:522)."""
+    y = ops.avg_pool(x, kernel, stride)
+    if ctx.tape is not None:
+        tape = ctx.tape
+        dims = tuple(x.shape[1:4])
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is not None:
+                tape.put(x, ops.avg_pool_bwd(ops.dense(dy), dims, kernel, stride))
+
+        tape.record(bwd)
+    return y
+
+
+def gn_act(ctx: Ctx, x, st, silu):
+    """act(GroupNorm(x)) as a tensor of its own (for consumers other than a conv prologue: the resamplers of
+    ResnetBlock(up / down), UNet:679-687).  Backward folds the other gradient branches of x in, like conv's fused path."""
+    y = ops.gn_apply(x, st, silu)
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            g = tape.take(y)
+            if g is None:
+                return
+            other = tape.take(x)
+            dx = ops.gn_bwd(g, x, st, ctx.p(st.name + ".weight"), silu, ctx.g(st.name + ".weight"), ctx.g(st.name + ".bias"), add=other)
+            tape.grads[id(x)] = dx
+            tape.keep.append(x)
+
+        tape.record(bwd)
+    return y
+
+
+def add(ctx: Ctx, a, b, b_needs_grad=True):
+    """a + b (ControlNet residual inputs, UNet:1995-2010)."""
+    y = ops.add(a, b)
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is not None:
+                tape.put(a, dy)
+                if b_needs_grad:
+                    tape.put(b, dy)
+
+        tape.record(bwd)
+    return y
+
+
+def resnet(ctx: Ctx, x, name, sd, groups, eps, addvec, d_addvec, mode=None, stride=None, kernel=None, out=None):
+    """ResnetBlock.forward (UNet:674-701): 2 statistics passes (mostly from the producing convs' epilogues) + 3 fused convs.
+    addvec: fp32 [N, Cout] = time_emb_proj(silu(emb)) + conv1.bias; d_addvec receives conv1's per-image dy column sums.
+    mode: None | 'up' (nearest x stride) | 'down' (avg-pool kernel/stride): both x and act(norm1(x)) are resampled (UNet:679-687).
+    out: where conv2 writes the block's result (the first channels of the next skip-concat buffer)."""
+    k3, s1, p1 = (1,) * (3 - sd) + (3,) * sd, (1, 1, 1), (0,) * (3 - sd) + (1,) * sd
+    name = name + "." if name else ""  # stand-alone blocks (blocks.ResnetBlock) have un-prefixed parameter names
+    n1 = gn(ctx, x, name + "norm1", groups, eps)
+    if mode is None:
+        h = conv(ctx, x, name + "conv1.conv", k3, s1, p1, norm=n1, silu=True, addvec=addvec, d_addvec=d_addvec)
+    else:
+        h = gn_act(ctx, x, n1, True)
+        if mode == "up":
+            x, h = upsample(ctx, x, stride), upsample(ctx, h, stride)
+        else:
+            x, h = avg_pool(ctx, x, kernel, stride), avg_pool(ctx, h, kernel, stride)
+        h = conv(ctx, h, name + "conv1.conv", k3, s1, p1, addvec=addvec, d_addvec=d_addvec)
+    n2 = gn(ctx, h, name + "norm2", groups, eps)
+    if name + "skip_connection.conv.weight" in ctx.arena.offsets:
+        xs = conv(ctx, x, name + "skip_connection.conv", (1, 1, 1), s1, (0, 0, 0), bias_grad_like=name + "conv2.conv")
+    else:
+        xs = x
+    return conv(ctx, h, name + "conv2.conv", k3, s1, p1, norm=n2, silu=True, res=xs, out=out)
 
 
 def concat_buffer(a_shape, ca, cb, device):
@@ -269,7 +409,7 @@ def concat(ctx: Ctx, a, b, buf=None):
         y = buf
     else:
         y = ops.concat_channels(a, b)
-    ctx.cat_parts[id(y)] = (a, b)
+    ctx.cat_parts[id(y)] = (a, b, weakref.ref(y))
     if ctx.tape is not None:
         tape = ctx.tape
         ca, cb = a.shape[-1], b.shape[-1]
@@ -346,8 +486,9 @@ def _attention_flash(ctx, x, name, st, xn, wqkv, qkv, b, s, c, heads, scale):
 def _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy, b, s, c):
     """Shared tail of the attention backward: projection weight/bias gradients, dx through the projections and the norm."""
     dev = x.device
-    gw = ctx.arena.span([f"{name}.to_{t}.weight" for t in "qkv"], ctx.arena.grad)
-    gb = ctx.arena.span([f"{name}.to_{t}.bias" for t in "qkv"], ctx.arena.grad)
+    pre = name + "." if name else ""
+    gw = ctx.arena.span([f"{pre}to_{t}.weight" for t in "qkv"], ctx.arena.grad)
+    gb = ctx.arena.span([f"{pre}to_{t}.bias" for t in "qkv"], ctx.arena.grad)
     # dW[3C, C] += dqkv^T xn and db += colsum(dqkv) in ONE pass over the two activations (no transposes, no long-K GEMM on 12 workgroups)
     call("mi_linear_wgrad_bf16", ptr(xn), c, c, ptr(dqkv), 3 * c, 3 * c, b * s, ptr(gw), ptr(gb))
     wqkv_t = _transpose(wqkv, c, 0, 0, 3 * c, c, 1, 1, dev)[0]           # [C, 3C]
@@ -355,7 +496,7 @@ def _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy,
     _gemm(dqkv, 3 * c, 0, 0, wqkv_t, 3 * c, 0, 0, dxn, c, 0, 0, b * s, c, 3 * c, 1, 1)
     other = tape.take(x)
     add = dy if other is None else ops.add(other, dy)
-    dx = ops.gn_bwd(dxn, x, st, ctx.p(name + ".norm.weight"), False, ctx.g(name + ".norm.weight"), ctx.g(name + ".norm.bias"), add=add)
+    dx = ops.gn_bwd(dxn, x, st, ctx.p(pre + "norm.weight"), False, ctx.g(pre + "norm.weight"), ctx.g(pre + "norm.bias"), add=add)
     tape.grads[id(x)] = dx
     tape.keep.append(x)
 
@@ -368,23 +509,37 @@ def attention(ctx: Ctx, x, name, groups, eps, heads):
     hd = c // heads
     scale = 1.0 / math.sqrt(c / heads)
     dev = x.device
-    st = gn(ctx, x, name + ".norm", groups, eps)
+    pre = name + "." if name else ""  # stand-alone blocks (blocks.AttentionBlock) have un-prefixed parameter names
+    st = gn(ctx, x, pre + "norm", groups, eps)
     xn = ops.gn_apply(x, st, False)                                              # [B, S, C]
-    wqkv = ops.cast_bf16(ctx.arena.span([f"{name}.to_{t}.weight" for t in "qkv"]).view(3 * c, c))
-    bqkv = ctx.arena.span([f"{name}.to_{t}.bias" for t in "qkv"])
+    wqkv = ops.cast_bf16(ctx.arena.span([f"{pre}to_{t}.weight" for t in "qkv"]).view(3 * c, c))
+    bqkv = ctx.arena.span([f"{pre}to_{t}.bias" for t in "qkv"])
     qkv = torch.empty((b * s, 3 * c), dtype=BF16, device=dev)
     _gemm(xn, c, 0, 0, wqkv, c, 0, 0, qkv, 3 * c, 0, 0, b * s, 3 * c, c, 1, 1, bias=bqkv)
     z = b * heads
     sq = s * 3 * c  # batch stride of qkv
     if FLASH_ATTENTION and _lib.call_raw("mi_attn_supported", c, heads):
         return _attention_flash(ctx, x, name, st, xn, wqkv, qkv, b, s, c, heads, scale)
+    # Materialised path (head dims the fused kernels do not cover).  Every bf16 matrix whose LAST axis is the token axis is a GEMM
+    # operand reduced over that axis: the NT GEMM loads 16-byte pieces along K, so those matrices get a row pitch `sp` = S rounded
+    # up to a multiple of 8 with zero pad columns (written by the softmax / transpose kernels themselves) and the products run
+    # over K = sp.  (3^3 = 27 or 5^3 = 125 tokens at the coarsest level of non-power-of-two patches.)
+    sp = (s + 7) // 8 * 8
     scores = torch.empty((z, s, s), dtype=F32, device=dev)
     _gemm((qkv, 0), 3 * c, sq, hd, (qkv, c), 3 * c, sq, hd, scores, s, heads * s * s, s * s, s, s, hd, z, heads, alpha=scale)
-    probs = ops.softmax_fwd(scores)
+    probs = ops.softmax_fwd(scores, pad8=True)                                    # [z, S, S] view, pitch sp
     del scores
-    vt = _transpose((qkv, 2 * c), 3 * c, sq, hd, s, hd, z, heads, dev)            # [z, hd, S]
+
+    def tr_tokens(src, ld_in, si1, si2, cols):
+        """[z][S][cols] (strided) -> [z][cols][sp] with the token axis last, zero padded."""
+        out = torch.empty((z, cols, sp), dtype=BF16, device=dev)
+        a = src[0].data_ptr() + src[1] * 2 if isinstance(src, tuple) else src.data_ptr()
+        call("mi_transpose_bf16", a, ld_in, si1, si2, ptr(out), sp, heads * cols * sp, cols * sp, s, cols, z, heads)
+        return out
+
+    vt = tr_tokens((qkv, 2 * c), 3 * c, sq, hd, hd)                               # [z, hd, sp]
     y = torch.empty_like(x)
-    _gemm(probs, s, heads * s * s, s * s, vt, s, heads * hd * s, hd * s, (y, 0), c, s * c, hd, s, hd, s, z, heads,
+    _gemm(probs, sp, heads * s * sp, s * sp, vt, sp, heads * hd * sp, hd * sp, (y, 0), c, s * c, hd, s, hd, sp, z, heads,
           res=(x, 0), ldr=c, sr1=s * c, sr2=hd)
     ctx.count(2 * b * s * c * 3 * c)       # q, k, v projections
     ctx.count(4 * b * s * s * c)           # QK^T and PV
@@ -397,18 +552,18 @@ def attention(ctx: Ctx, x, name, groups, eps, heads):
                 return
             dp = torch.empty((z, s, s), dtype=F32, device=dev)
             _gemm((dy, 0), c, s * c, hd, (qkv, 2 * c), 3 * c, sq, hd, dp, s, heads * s * s, s * s, s, s, hd, z, heads)
-            ds = ops.softmax_bwd(probs, dp, scale)
+            ds = ops.softmax_bwd(probs, dp, scale)                                # [z, S, S] view, pitch sp
             del dp
             dqkv = torch.empty((b * s, 3 * c), dtype=BF16, device=dev)
-            kt = _transpose((qkv, c), 3 * c, sq, hd, s, hd, z, heads, dev)
-            _gemm(ds, s, heads * s * s, s * s, kt, s, heads * hd * s, hd * s, (dqkv, 0), 3 * c, sq, hd, s, hd, s, z, heads)
-            qt = _transpose((qkv, 0), 3 * c, sq, hd, s, hd, z, heads, dev)
-            dst = _transpose(ds, s, heads * s * s, s * s, s, s, z, heads, dev)
-            _gemm(dst, s, heads * s * s, s * s, qt, s, heads * hd * s, hd * s, (dqkv, c), 3 * c, sq, hd, s, hd, s, z, heads)
+            kt = tr_tokens((qkv, c), 3 * c, sq, hd, hd)
+            _gemm(ds, sp, heads * s * sp, s * sp, kt, sp, heads * hd * sp, hd * sp, (dqkv, 0), 3 * c, sq, hd, s, hd, sp, z, heads)
+            qt = tr_tokens((qkv, 0), 3 * c, sq, hd, hd)
+            dst = tr_tokens(ds, sp, heads * s * sp, s * sp, s)                    # dS^T [z, S, sp]
+            _gemm(dst, sp, heads * s * sp, s * sp, qt, sp, heads * hd * sp, hd * sp, (dqkv, c), 3 * c, sq, hd, s, hd, sp, z, heads)
             del dst, ds
-            pt = _transpose(probs, s, heads * s * s, s * s, s, s, z, heads, dev)
-            dot = _transpose((dy, 0), c, s * c, hd, s, hd, z, heads, dev)
-            _gemm(pt, s, heads * s * s, s * s, dot, s, heads * hd * s, hd * s, (dqkv, 2 * c), 3 * c, sq, hd, s, hd, s, z, heads)
+            pt = tr_tokens(probs, sp, heads * s * sp, s * sp, s)                  # P^T [z, S, sp]
+            dot = tr_tokens((dy, 0), c, s * c, hd, hd)
+            _gemm(pt, sp, heads * s * sp, s * sp, dot, sp, heads * hd * sp, hd * sp, (dqkv, 2 * c), 3 * c, sq, hd, s, hd, sp, z, heads)
             del pt
             _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy, b, s, c)
 
@@ -429,9 +584,9 @@ def linear_f32(x_f32, w, b, gw, gb):
         """dy may be a column slice; accumulates into the weight/bias gradients, returns dx (fp32) or None."""
         dyb = ops.cast_bf16(dy_f32)
         ops.sum_rows_f32(dy_f32, gb, accumulate=True)
-        mp = (m + 7) // 8 * 8  # K of the weight-gradient GEMM must be a multiple of 8: zero-padded transposes
-        dy_t = torch.zeros((out_f, mp), dtype=BF16, device=dy_f32.device)
-        x_t = torch.zeros((in_f, mp), dtype=BF16, device=dy_f32.device)
+        mp = (m + 7) // 8 * 8  # K of the weight-gradient GEMM must be a multiple of 8: the transpose kernel zero-fills [m, mp)
+        dy_t = torch.empty((out_f, mp), dtype=BF16, device=dy_f32.device)
+        x_t = torch.empty((in_f, mp), dtype=BF16, device=dy_f32.device)
         call("mi_transpose_bf16", ptr(dyb), out_f, 0, 0, ptr(dy_t), mp, 0, 0, m, out_f, 1, 1)
         call("mi_transpose_bf16", ptr(xb), in_f, 0, 0, ptr(x_t), mp, 0, 0, m, in_f, 1, 1)
         _gemm(dy_t, mp, 0, 0, x_t, mp, 0, 0, gw, in_f, 0, 0, out_f, in_f, mp, 1, 1, accumulate=True)

@@ -58,7 +58,8 @@ def to_channels_first(x_cl: torch.Tensor, spatial_dims: int = 3) -> torch.Tensor
 
 
 def add(a, b):
-    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    a, b = dense(a), dense(b)
+    assert a.shape == b.shape
     out = torch.empty_like(a)
     call("mi_add_bf16", ptr(a), ptr(b), ptr(out), a.numel())
     return out
@@ -80,6 +81,12 @@ def slice_channels(x, c0, nc):
     return out
 
 
+def dense(t):
+    """A channel-slice view of a wider channels-last buffer (the gradient hand-off of an in-place concat) as a dense tensor; dense
+    tensors pass through.  Our copy kernel, not aten."""
+    return t if t.is_contiguous() else slice_channels(t, 0, t.shape[-1])
+
+
 def upsample_nearest(x, f):
     n, d, h, w, c = x.shape
     out = torch.empty((n, d * f[0], h * f[1], w * f[2], c), dtype=BF16, device=x.device)
@@ -92,6 +99,30 @@ def upsample_nearest_bwd(dy, f):
     out = torch.empty((n, d // f[0], h // f[1], w // f[2], c), dtype=BF16, device=dy.device)
     call("mi_upsample_nearest_bwd", ptr(dy), ptr(out), n, d // f[0], h // f[1], w // f[2], c, f[0], f[1], f[2])
     return out
+
+
+def _pool_out(dims, kernel, stride):
+    return tuple((d - k) // s + 1 for d, k, s in zip(dims, kernel, stride))
+
+
+def avg_pool(x, kernel, stride):
+    """nn.AvgPool{2,3}d(kernel_size, stride) (no padding, floor mode) on NDHWC bf16."""
+    n, d, h, w, c = x.shape
+    assert x.is_contiguous()
+    od, oh, ow = _pool_out((d, h, w), kernel, stride)
+    out = torch.empty((n, od, oh, ow, c), dtype=BF16, device=x.device)
+    arr = lambda v: (C.c_int * 3)(*v)
+    call("mi_avgpool_fwd", ptr(x), ptr(out), n, d, h, w, c, arr(kernel), arr(stride))
+    return out
+
+
+def avg_pool_bwd(dy, in_dims, kernel, stride):
+    n, c = dy.shape[0], dy.shape[-1]
+    assert dy.is_contiguous() and tuple(dy.shape[1:4]) == _pool_out(in_dims, kernel, stride)
+    dx = torch.empty((n,) + tuple(in_dims) + (c,), dtype=BF16, device=dy.device)
+    arr = lambda v: (C.c_int * 3)(*v)
+    call("mi_avgpool_bwd", ptr(dy), ptr(dx), n, in_dims[0], in_dims[1], in_dims[2], c, arr(kernel), arr(stride))
+    return dx
 
 
 # ----------------------------------------------------------------------------- GroupNorm
@@ -308,17 +339,24 @@ def transpose(x):
     return out if x.dim() == 3 else out[0]
 
 
-def softmax_fwd(scores_f32):
+def softmax_fwd(scores_f32, pad8=False):
+    """bf16 row softmax of dense fp32 scores.  pad8: the result's row pitch is the column count rounded up to a multiple of 8, pad
+    columns zero (returned as a [..., cols] view of the padded buffer) -- what the NT GEMM needs when it reduces over this axis."""
     s = scores_f32.contiguous()
-    out = torch.empty(s.shape, dtype=BF16, device=s.device)
-    call("mi_softmax_fwd", ptr(s), ptr(out), s.numel() // s.shape[-1], s.shape[-1])
-    return out
+    cols = s.shape[-1]
+    ld = (cols + 7) // 8 * 8 if pad8 else cols
+    out = torch.empty(s.shape[:-1] + (ld,), dtype=BF16, device=s.device)
+    call("mi_softmax_fwd", ptr(s), ptr(out), s.numel() // cols, cols, ld)
+    return out[..., :cols]
 
 
 def softmax_bwd(probs, dprobs_f32, scale):
-    out = torch.empty(probs.shape, dtype=BF16, device=probs.device)
-    call("mi_softmax_bwd", ptr(probs), ptr(dprobs_f32), ptr(out), probs.numel() // probs.shape[-1], probs.shape[-1], float(scale))
-    return out
+    """probs: as returned by softmax_fwd (possibly a view of a padded buffer: the result has the same pitch, pad columns zero)."""
+    cols, ld = probs.shape[-1], probs.stride(-2)
+    assert probs.stride(-1) == 1 and dprobs_f32.is_contiguous()
+    out = torch.empty(probs.shape[:-1] + (ld,), dtype=BF16, device=probs.device)
+    call("mi_softmax_bwd", ptr(probs), ptr(dprobs_f32), ptr(out), probs.numel() // cols, cols, ld, float(scale))
+    return out[..., :cols]
 
 
 # ----------------------------------------------------------------------------- small ops

@@ -108,6 +108,7 @@ class _Loop:
         self.arena = model.arena(device)
         self.graph = None
         self.keys = ()  # conv plans whose weights are packed: once per run(), not per step (the weights do not change while sampling)
+        self._pinned = None  # objects whose device memory the captured graph points at (conv plans, GroupNorm workspace)
 
     def _step(self):
         ctx = E.Ctx(self.arena, self.m._plans, grad_enabled=False, prepacked=self.keys)
@@ -116,6 +117,8 @@ class _Loop:
              int(self.sch.clip_sample) | (2 if self.sch.prediction_type == "v_prediction" else 0))
 
     def run(self, input_noise, noises=None, generator=None, use_graph=True, on_step=None):
+        if self.m._arena is not self.arena:  # the module moved (.to / .cuda): plans and graph point at the old buffers -> start over
+            self.arena, self.graph, self.keys, self._pinned = self.m.arena(self.x.device), None, (), None
         self.x.copy_(input_noise)
         self.x_cl.copy_(ops.to_channels_last(self.x))
         steps = [int(t) for t in self.sch.timesteps]
@@ -136,6 +139,7 @@ class _Loop:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self._step()
+            self._pinned = (dict(self.m._plans), dict(ops._ws_cache), self.arena)  # keep what the graph points at alive
         self.x.copy_(keep)
         self.x_cl.copy_(ops.to_channels_last(self.x))
         for i, t in enumerate(steps):
@@ -167,6 +171,16 @@ class DiffusionInferer:
             self._loops[key] = _Loop(model, scheduler, tuple(shape), device)
         return self._loops[key]
 
+    def __call__(self, inputs, diffusion_model, noise, timesteps, condition=None, mode="crossattn"):
+        """The training-side call of train_ddpm.py:191: `noise_pred = inferer(inputs=images, diffusion_model=model, noise=noise,
+        timesteps=timesteps)` = diffusion_model(scheduler.add_noise(inputs, noise, timesteps), timesteps) (third-party
+        `generative.inferers.DiffusionInferer.__call__`).  Differentiable through the model's autograd edge; the fused
+        trainer.DDPMTrainer is the fast path for the same computation."""
+        if condition is not None:
+            raise NotImplementedError("conditioning is not on the HIP path (unused by the reference's configs)")
+        noisy = self.scheduler.add_noise(original_samples=inputs, noise=noise, timesteps=timesteps)
+        return diffusion_model(x=noisy, timesteps=timesteps)
+
     @torch.no_grad()
     def sample(self, input_noise, diffusion_model, scheduler=None, save_intermediates=False, intermediate_steps=100, conditioning=None,
                mode="crossattn", verbose=True, noises=None, generator=None, use_graph=True):
@@ -194,6 +208,13 @@ class LatentDiffusionInferer(DiffusionInferer):
     def __init__(self, scheduler, scale_factor=1.0):
         super().__init__(scheduler)
         self.scale_factor = scale_factor
+
+    def __call__(self, inputs, autoencoder_model, diffusion_model, noise, timesteps, condition=None, mode="crossattn"):
+        """`generative.inferers.LatentDiffusionInferer.__call__`: encode (no grad) -> * scale_factor -> DiffusionInferer.__call__."""
+        with torch.no_grad():
+            latent = autoencoder_model.encode_stage_2_inputs(inputs) * self.scale_factor
+        return super().__call__(inputs=latent, diffusion_model=diffusion_model, noise=noise, timesteps=timesteps, condition=condition,
+                                mode=mode)
 
     @torch.no_grad()
     def sample(self, input_noise, autoencoder_model, diffusion_model, scheduler=None, save_intermediates=False, intermediate_steps=100,

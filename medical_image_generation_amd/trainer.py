@@ -46,9 +46,18 @@ class DDPMSchedule:
 
 
 class _ArenaTrainer:
-    """Optimizer state over the flat arena, gradient averaging and hipGraph capture; subclasses give forward_backward()."""
+    """Optimizer state over the flat arena, gradient accumulation, data-parallel gradient exchange and hipGraph capture;
+    subclasses give forward_backward().
 
-    def __init__(self, model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device):
+    Data parallelism: the backward pass is cut ONCE, at the point where every gradient of the arena's *early* segment
+    [arena.n_late, arena.n_trainable) is final (HipModule orders the arena so: the parameters whose gradients complete last -- the
+    finest-resolution levels, conv_in and everything the time-embedding backward writes -- form the *late* prefix).  The SUM
+    all-reduce of the early segment (>= 95 % of the bytes) is issued asynchronously at the cut and runs over xGMI while the rest of
+    the backward (the full-resolution layers: ~1/3 of its time, almost no parameters) computes; the small late segment follows.
+    The mean is never materialised: 1/world is folded into the optimizer kernel (`grad_scale`)."""
+
+    def __init__(self, model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device,
+                 grad_accumulate_step=1):
         self.model = model
         self.device = torch.device(device or "cuda")
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -60,6 +69,9 @@ class _ArenaTrainer:
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (process_group is not None or dist.is_initialized()) else 1
         self.bucket_elems = bucket_mb * (1 << 20) // 4
+        if int(grad_accumulate_step) < 1:
+            raise ValueError("grad_accumulate_step must be >= 1")
+        self.grad_accumulate_step = int(grad_accumulate_step)
         self.arena = model.arena(self.device)
         if self.world > 1:
             ddp.broadcast_parameters(self.arena.data, 0, process_group)
@@ -69,13 +81,53 @@ class _ArenaTrainer:
         self.step_count = torch.zeros(1, dtype=F32, device=self.device)
         self.sumsq = torch.zeros(1, dtype=F32, device=self.device)
         self.loss = torch.zeros(1, dtype=F32, device=self.device)
+        self._accum = None       # fp32 [n_trainable]: sum of the gradients of the pending micro-steps (grad_accumulate_step > 1)
+        self._micro = 0          # micro-steps since the last optimizer step
         self._graph = None
         self._static = None
+        self._force_split = False  # tests: capture the two-graph form with world 1
 
     # ------------------------------------------------------------------ pieces
+    def _forward(self, *inputs):
+        """-> (tape, out, dout): the network forward and the loss gradient at its output (subclasses)."""
+        raise NotImplementedError
+
+    def _fb_begin(self, *inputs):
+        """Forward + the backward up to the model's cut mark (engine.CUT; the whole backward when nothing was marked).  Returns the
+        state _fb_finish needs; it also keeps every tensor that is live across the cut alive, so the two halves can be captured
+        into two hipGraphs sharing one memory pool."""
+        tape, out, dout = self._forward(*inputs)
+        tape.put(out, dout)
+        fns, tape.fns = tape.fns, []
+        i = len(fns)
+        while i > 0:
+            i -= 1
+            if fns[i] is E.CUT:
+                break
+            fns[i]()
+        return tape, fns[:i]
+
+    def _fb_finish(self, state):
+        tape, rest = state
+        for fn in reversed(rest):
+            fn()  # (a second CUT mark is a no-op)
+        tape.grads.clear(), tape.keep.clear()
+
+    def forward_backward(self, *inputs, on_cut=None):
+        """Fresh gradients of one (micro-)batch into arena.grad, loss into self.loss.  on_cut(): called where every gradient of the
+        arena's early segment [n_late, n_trainable) is final (data-parallel overlap)."""
+        state = self._fb_begin(*inputs)
+        if on_cut is not None:
+            on_cut()
+        self._fb_finish(state)
+
+    def _exchange(self):
+        return ddp.GradientExchange(self.arena.grad, self.arena.n_late, self.arena.n_trainable, self.pg, self.bucket_elems)
+
     def all_reduce_grads(self):
+        """SUM all-reduce of the whole trainable gradient prefix, no overlap (the mean is taken by the optimizer's grad_scale)."""
         if self.world > 1:
-            ddp.average_gradients(self.arena.grad, self.arena.n_trainable, self.pg, self.bucket_elems)
+            self._exchange().finish()
 
     def optimizer_step(self):
         a = self.arena
@@ -85,19 +137,49 @@ class _ArenaTrainer:
             call("mi_sumsq_f32", ptr(a.grad), n, ptr(self.sumsq), 0)
         call("mi_adam_step", ptr(a.data), ptr(a.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), n, self.lr, self.betas[0], self.betas[1],
              self.eps, self.weight_decay, int(self.decoupled), ptr(self.sumsq) if clip else None, float(self.max_grad_norm or 0.0),
-             ptr(self.step_count))
+             1.0 / self.world, ptr(self.step_count))
+
+    # ------------------------------------------------------------------ gradient accumulation (T-LDM:173-180, T-AE:389-397)
+    def _fold_micro_step(self, boundary):
+        """The reference sums the micro-step gradients (loss NOT divided) and clips / steps / zeroes on the boundary.  Every
+        forward_backward() writes a fresh gradient into arena.grad; pending micro-steps live in a side buffer, so kernels that
+        COPY gradients between tensors (a shortcut conv's bias gradient) never see stale sums."""
+        n = self.arena.n_trainable
+        if not boundary:
+            if self._accum is None:
+                self._accum = torch.empty(n, dtype=F32, device=self.device)
+                call("mi_zero_f32_2d", ptr(self._accum), n, 1, n)
+            call("mi_axpy_f32", ptr(self._accum), ptr(self.arena.grad), 1.0, n)
+            self._micro += 1
+            return
+        if self._micro:
+            call("mi_axpy_f32", ptr(self.arena.grad), ptr(self._accum), 1.0, n)
+            call("mi_zero_f32_2d", ptr(self._accum), n, 1, n)
+        self._micro = 0
 
     # ------------------------------------------------------------------ one step
-    def step(self, *inputs):
-        """Eager step; returns the (device) loss tensor without synchronising."""
-        self.forward_backward(*inputs)
-        self.all_reduce_grads()
+    def step(self, *inputs, last_in_epoch=False):
+        """One (micro-)step, eager; returns the (device) loss tensor of this micro-batch without synchronising.  With
+        grad_accumulate_step = k the optimizer runs on every k-th call (or when last_in_epoch, T-LDM:173); the data-parallel
+        exchange happens on that boundary micro-step only."""
+        boundary = (self._micro + 1) % self.grad_accumulate_step == 0 or last_in_epoch
+        ex = self._exchange() if self.world > 1 and boundary else None
+        # the early segment may leave at the cut only when no pending micro-step sum has to be folded in first
+        self.forward_backward(*inputs, on_cut=ex.start_early if ex is not None and self._micro == 0 else None)
+        self._fold_micro_step(boundary)
+        if not boundary:
+            return self.loss
+        if ex is not None:
+            ex.finish()
         self.optimizer_step()
         return self.loss
 
     def capture(self, *inputs, warmup=2):
-        """Capture forward+backward and the optimizer as hipGraphs around static input buffers (the all-reduce stays
-        eager between them so RCCL is never inside a capture).  Call step_graph() afterwards."""
+        """Capture the step as hipGraphs around static input buffers; call step_graph() afterwards.  Graphs: forward + the backward up
+        to the cut, the rest of the backward (only when there is something to overlap: world > 1), the optimizer.  RCCL is never
+        inside a capture: the all-reduces are issued between the replays, the early segment's concurrently with the second graph."""
+        if self.grad_accumulate_step != 1:
+            raise RuntimeError("hipGraph capture covers grad_accumulate_step == 1; use step() for accumulation")
         self._static = tuple(t.clone() for t in inputs)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -106,23 +188,48 @@ class _ArenaTrainer:
                 self.forward_backward(*self._static)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        split = (self.world > 1 or self._force_split) and 0 < self.arena.n_late < self.arena.n_trainable
         # thread_local: a collective library's watchdog thread polling events must not invalidate the capture
-        self._g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
-            self.forward_backward(*self._static)
+        self._g_fb, self._g_fb2 = torch.cuda.CUDAGraph(), None
+        if not split:
+            with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
+                self.forward_backward(*self._static)
+        else:
+            with torch.cuda.graph(self._g_fb, capture_error_mode="thread_local"):
+                state = self._fb_begin(*self._static)
+            self._g_fb2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_fb2, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
+                self._fb_finish(state)
+            del state
         self._g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_opt, capture_error_mode="thread_local"):
             self.optimizer_step()
         self._graph = True
+        # The graphs hold raw device pointers of objects Python owns: the PackBatch (group tables), every conv plan (packed weights,
+        # split slabs), the GroupNorm workspace and the arena.  Pin them for as long as the graphs exist -- a forward at another
+        # shape between train steps (validation, DiffusionInferer.sample) replaces model._packb / grows the workspace, and their
+        # destructors would hipFree memory the next replay still writes to.
+        self._pinned = [(m._packb, dict(m._plans), m._arena) for m in self._models()] + [dict(ops._ws_cache)]
+
+    def _models(self):
+        return [self.model]
 
     def step_graph(self, *inputs):
         """Replay; inputs given (positionally, None = keep) are copied into the static buffers first."""
         assert self._graph, "call capture() first"
+        if self.model._arena is not self.arena:  # .to() / .cuda() / load into new storage: the graphs point at the old buffers
+            raise RuntimeError("the model's parameter arena was rebuilt after capture(): create a new trainer (or call capture() again)")
         for buf, t in zip(self._static, inputs):
             if t is not None:
                 buf.copy_(t)
+        ex = self._exchange() if self.world > 1 else None
         self._g_fb.replay()
-        self.all_reduce_grads()
+        if self._g_fb2 is not None:
+            if ex is not None:
+                ex.start_early()   # early segment: final once the first graph is done ...
+            self._g_fb2.replay()   # ... and its all-reduce runs over xGMI while the rest of the backward computes
+        if ex is not None:
+            ex.finish()
         self._g_opt.replay()
         return self.loss
 
@@ -131,15 +238,25 @@ class DDPMTrainer(_ArenaTrainer):
     """step(x0, noise, timesteps[, class_labels]): x0/noise fp32 NCDHW, timesteps (and class_labels) int64 [N]."""
 
     def __init__(self, model, lr=2e-5, optimizer="AdamW", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
-                 schedule: DDPMSchedule | None = None, process_group=None, bucket_mb=64, device=None):
-        super().__init__(model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device)
+                 schedule: DDPMSchedule | None = None, process_group=None, bucket_mb=64, device=None, grad_accumulate_step=1):
+        super().__init__(model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device,
+                         grad_accumulate_step)
         self.schedule = schedule or DDPMSchedule(device=self.device)
 
-    def forward_backward(self, x0, noise, timesteps, class_labels=None):
-        """q-sample -> UNet -> MSE -> backward into the gradient arena.  x0/noise: fp32 NCDHW, timesteps: int64 [N];
-        class_labels: int64 [N], only for a net built with num_class_embeds."""
+    def _forward(self, x0, noise, timesteps, class_labels=None):
+        """q-sample -> UNet -> MSE (+ its gradient).  x0/noise: fp32 NCDHW, timesteps: int64 [N]; class_labels: int64 [N], only for
+        a net built with num_class_embeds."""
         m = self.model
         a = self.arena
+        # raw pointers go to the kernels: refuse anything they would misread instead of reading out of bounds
+        if not (x0.is_cuda and noise.is_cuda and timesteps.is_cuda):
+            raise RuntimeError("DDPMTrainer inputs must live on the GPU")
+        if x0.dtype != F32 or noise.dtype != F32 or not x0.is_contiguous() or not noise.is_contiguous() or x0.shape != noise.shape:
+            raise ValueError("x0 and noise must be contiguous fp32 tensors of the same NC[D]HW shape")
+        if timesteps.dtype != torch.int64 or timesteps.shape != (x0.shape[0],) or not timesteps.is_contiguous():
+            raise ValueError("timesteps must be a contiguous int64 tensor of shape [N]")  # range: clamped to the schedule in k_qsample
+        if x0.shape[1] != m.in_channels:
+            raise ValueError(f"Input number of channels ({x0.shape[1]}) is not equal to expected number of channels ({m.in_channels})")
         a.grad.zero_()
         sd = m.spatial_dims
         n, c = x0.shape[0], x0.shape[1]
@@ -152,15 +269,65 @@ class DDPMTrainer(_ArenaTrainer):
         vpred = self.schedule.prediction_type == "v_prediction"  # target = scheduler.get_velocity(x0, noise, t), T-LDM:163-165
         target = torch.empty_like(noise) if vpred else noise
         call("mi_qsample", ptr(x0), ptr(noise), ptr(self.schedule.sqrt_acp), ptr(self.schedule.sqrt_1macp), ptr(timesteps), ptr(x_t),
-             ptr(target) if vpred else None, n, c, v)
+             ptr(target) if vpred else None, n, c, v, self.schedule.num_train_timesteps)
         ctx = E.Ctx(a, m._plans, grad_enabled=True, prepacked=m.pack_all())
         if (class_labels is None) != (getattr(m, "num_class_embeds", None) is None):
             raise ValueError("class_labels should be provided exactly when the model has num_class_embeds")
         pred = m._run(ctx, x_t, timesteps, need_dx=False, class_labels=class_labels)
         dpred = torch.empty_like(pred)
         call("mi_mse_fwd_bwd", ptr(pred), ptr(target), ptr(dpred), ptr(self.loss), n, pred.shape[-1], v, 1.0)
-        ctx.tape.backward(pred, dpred)
-        ctx.tape.grads.clear(), ctx.tape.keep.clear()
+        self._keep = (x_t, target)  # read by kernels still in flight / by the second graph of a split capture
+        return ctx.tape, pred, dpred
+
+
+class LDMTrainer(DDPMTrainer):
+    """The latent-diffusion train step as train_ldm.LDM.train_one_epoch runs it (T-LDM:145-180, 'vae' branch):
+
+        latents = autoencoder.encode_stage_2_inputs(images)   (no grad: T-LDM:154-156)  ->  * scale_factor  ->  q-sample -> UNet
+        -> MSE -> backward -> clip -> AdamW
+
+    step(images, eps, noise, timesteps): images fp32 NC[D]HW; eps fp32, latent-shaped -- the torch.randn_like of
+    AutoencoderKL.sampling (AEKL:786-787) made an input so that a captured graph sees fresh noise and tests can pin it; noise fp32,
+    latent-shaped (T-LDM:159); timesteps int64 [N].  The encoder runs tape-less on the same HIP kernels inside the same hipGraph.
+    `scale_factor`: 1 / std of the first batch's latents (T-LDM:110-112) -- `estimate_scale_factor` -- or given."""
+
+    def __init__(self, model, autoencoder, scale_factor: float | None = None, **kw):
+        super().__init__(model, **kw)
+        self.autoencoder = autoencoder
+        self.ae_arena = autoencoder.arena(self.device)
+        self.scale_factor = None if scale_factor is None else float(scale_factor)
+
+    def _models(self):
+        return [self.model, self.autoencoder]
+
+    def _latents(self, images, eps):
+        """encode_stage_2_inputs (AEKL:827-830): z = z_mu + eps * z_sigma, fp32 NC[D]HW, unscaled; no tape."""
+        ae = self.autoencoder
+        if images.dtype != F32 or not images.is_cuda or not images.is_contiguous() or eps.dtype != F32 or not eps.is_contiguous():
+            raise ValueError("images and eps must be contiguous fp32 GPU tensors")
+        x_cl = ops.to_channels_last(images)
+        ctx = E.Ctx(self.ae_arena, ae._plans, grad_enabled=False, prepacked=ae.pack_all())
+        mu, sigma = ae._encode_run(ctx, x_cl, need_dx=False)
+        n, lc = mu.shape[0], mu.shape[-1]
+        lv = mu.numel() // (n * lc)
+        if tuple(eps.shape) != (n, lc) + tuple(d for d in mu.shape[1:4])[3 - ae.spatial_dims:]:
+            raise ValueError(f"eps must have the latent shape, got {tuple(eps.shape)}")
+        z = torch.empty_like(mu)
+        call("mi_reparam_kl_fwd", ptr(mu), ptr(sigma), ptr(eps), ptr(z), None, n, lc, lv, 0.0)
+        return ops.to_channels_first(z, ae.spatial_dims)
+
+    @torch.no_grad()
+    def estimate_scale_factor(self, images, eps):
+        """scale_factor = 1 / std(z) over the first batch (T-LDM:110-112); stored and returned."""
+        self.scale_factor = float(1.0 / torch.std(self._latents(images, eps)))
+        return self.scale_factor
+
+    def _forward(self, images, eps, noise, timesteps, class_labels=None):
+        if self.scale_factor is None:
+            raise RuntimeError("scale_factor is not set: pass it or call estimate_scale_factor(first_batch, eps) (train_ldm.py:110-112)")
+        z = self._latents(images, eps)
+        call("mi_scale_f32", ptr(z), self.scale_factor, z.numel())  # latents_scaled = latents * inferer.scale_factor (T-LDM:157)
+        return super()._forward(z, noise, timesteps, class_labels)
 
 
 class AETrainer(_ArenaTrainer):
@@ -169,11 +336,12 @@ class AETrainer(_ArenaTrainer):
     optimizer (Adam, lr 5e-5, grad_clip_max_norm 1; T-AE:428-434, 470) and 3-D kl_weight (CFG:995-1026)."""
 
     def __init__(self, model, lr=5e-5, optimizer="Adam", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
-                 kl_weight=1e-7, process_group=None, bucket_mb=64, device=None):
-        super().__init__(model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device)
+                 kl_weight=1e-7, process_group=None, bucket_mb=64, device=None, grad_accumulate_step=1):
+        super().__init__(model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device,
+                         grad_accumulate_step)
         self.kl_weight = float(kl_weight)
 
-    def forward_backward(self, images, eps):
+    def _forward(self, images, eps):
         m, a = self.model, self.arena
         a.grad.zero_()
         self.loss.zero_()
@@ -201,5 +369,4 @@ class AETrainer(_ArenaTrainer):
         recon = m._decode_run(ctx, z, True)
         drecon = torch.empty_like(recon)
         call("mi_l1_fwd_bwd", ptr(recon), ptr(images), ptr(drecon), ptr(self.loss), n, recon.shape[-1], v, 1)
-        tape.backward(recon, drecon)
-        tape.grads.clear(), tape.keep.clear()
+        return tape, recon, drecon

@@ -5,8 +5,9 @@ keywords, same `forward(x, timesteps, ...)`, same `state_dict()` names and shape
 ValueError conditions.  Forward and backward run entirely on hand-written HIP kernels (channels-last bf16
 activations, fp32 accumulate / statistics / gradients); PyTorch provides memory, streams and the autograd edge.
 
-Not implemented on the HIP path (raise NotImplementedError, all unused by the reference's own configs, SURVEY 2
-rows 5 and 2a): cross-attention conditioning, class embeddings, `resblock_updown`, xformers flash attention.
+Also on the HIP path: class embeddings (`num_class_embeds`), `resblock_updown=True` (avg-pool / nearest resnet resamplers,
+UNet:640-644, 679-687) and ControlNet residual inputs (UNet:1995-2010).  Not implemented (raise NotImplementedError; never
+enabled by the reference's own configs): cross-attention conditioning, xformers flash attention.
 """
 from __future__ import annotations
 
@@ -86,28 +87,35 @@ class ParamSpec:
         self._add(name + ".bias", torch.zeros(c))
 
     def attention(self, name, c):
-        self.norm(name + ".norm", c)
+        pre = name + "." if name else ""
+        self.norm(pre + "norm", c)
         for n in ("to_q", "to_k", "to_v"):
-            self.linear(f"{name}.{n}", c, c)
-        self.linear(name + ".proj_attn", c, c, trainable=False)  # constructed, never called (UNet:383 vs 418-458)
+            self.linear(pre + n, c, c)
+        self.linear(pre + "proj_attn", c, c, trainable=False)  # constructed, never called (UNet:383 vs 418-458)
 
 
-def arena_order(entries, groups):
-    """Reorder (name, shape, trainable) so that every list in `groups` is adjacent and in the given order."""
+def arena_order(entries, groups, late=()):
+    """Reorder (name, shape, trainable) so that every list in `groups` is adjacent and in the given order, then move the tensors
+    named in `late` (gradients complete last in the backward pass; a group is late as a whole or not at all) to the front, keeping
+    the relative order: the arena becomes [late | early | untrainable] (engine.ParamArena)."""
     grouped = {n for g in groups for n in g}
     by_name = {e[0]: e for e in entries}
     out = []
     for g in groups:
         out.extend(by_name[n] for n in g)
     out.extend(e for e in entries if e[0] not in grouped)
-    return out
+    late = set(late)
+    for g in groups:
+        assert len({n in late for n in g}) <= 1, f"group straddles the late / early split: {g[0]} ..."
+    return [e for e in out if e[0] in late and e[2]] + [e for e in out if not (e[0] in late and e[2])]
 
 
 class HipModule(nn.Module):
     """Shared plumbing: flat parameter arena on the device, conv-plan cache, autograd edge."""
 
-    def _init_plumbing(self, spec: ParamSpec, groups):
-        self._entries = arena_order(spec.order, groups)
+    def _init_plumbing(self, spec: ParamSpec, groups, late=()):
+        self._late = tuple(n for n in late)
+        self._entries = arena_order(spec.order, groups, self._late)
         self._arena = None
         self._plans = {}
         self._packb = None
@@ -118,7 +126,7 @@ class HipModule(nn.Module):
         a = self._arena
         first = self._entries[0][0]
         if a is None or a.data.device != device or params[first].data_ptr() != a.view(first).data_ptr():
-            a = E.ParamArena(self._entries, device)
+            a = E.ParamArena(self._entries, device, late=self._late)
             for name, _, _ in self._entries:
                 v = a.view(name)
                 v.copy_(params[name].data)
@@ -147,17 +155,20 @@ class HipModule(nn.Module):
 
 
 class _NetFn(torch.autograd.Function):
-    """Autograd edge of a whole network: forward = tape forward, backward = tape backward on HIP kernels."""
+    """Autograd edge of a whole network (or block): forward = tape forward, backward = tape backward on HIP kernels.
+    `emb` is an optional second differentiable input (the time embedding of a stand-alone ResnetBlock); runners that take it
+    return extra["d_emb"], a callable evaluated after the tape has run."""
 
     @staticmethod
-    def forward(ctx, module, runner, nouts, grad_enabled, x, *params):
+    def forward(ctx, module, runner, nouts, grad_enabled, x, emb, *params):
         dev = x.device
         ctx.set_materialize_grads(False)  # unused outputs (e.g. z_sigma) arrive as None, not as zero tensors
         arena = module.arena(dev)
         c = E.Ctx(arena, module._plans, grad_enabled=grad_enabled, prepacked=module.pack_all())  # (autograd disables grad mode inside forward)
         need_dx = bool(grad_enabled and ctx.needs_input_grad[4])
-        outs_cl, extra = runner(c, x, need_dx)
+        outs_cl, extra = runner(c, x, need_dx) if emb is None else runner(c, x, need_dx, emb)
         ctx.c, ctx.module, ctx.outs_cl, ctx.need_dx, ctx.extra = c, module, outs_cl, need_dx, extra
+        ctx.need_demb = bool(emb is not None and grad_enabled and ctx.needs_input_grad[5])
         ctx.sd = module.spatial_dims
         ctx.names = [n for n, _ in module.named_parameters()]
         outs = tuple(ops.to_channels_first(o, ctx.sd) for o in outs_cl)
@@ -178,11 +189,12 @@ class _NetFn(torch.autograd.Function):
         dx = None
         if ctx.need_dx:
             g = tape.take(ctx.extra["x_cl"])
-            dx = ops.to_channels_first(g, ctx.sd) if g is not None else None
+            dx = ops.to_channels_first(ops.dense(g), ctx.sd) if g is not None else None
+        demb = ctx.extra["d_emb"]() if ctx.need_demb else None
         trainable = {n for n, _, t in ctx.module._entries if t}
         grads = tuple(arena.gview(n).clone() if n in trainable else None for n in ctx.names)
         tape.grads.clear(), tape.keep.clear()
-        return (None, None, None, None, dx) + grads
+        return (None, None, None, None, dx, demb) + grads
 
 
 class DiffusionModelUNet(HipModule):
@@ -233,8 +245,8 @@ class DiffusionModelUNet(HipModule):
                              "`num_channels`.")
         if use_flash_attention:
             raise ValueError("use_flash_attention is True but xformers is not installed.")
-        if with_conditioning or resblock_updown:
-            raise NotImplementedError("cross-attention / resblock_updown are not on the HIP path yet "
+        if with_conditioning:
+            raise NotImplementedError("cross-attention conditioning is not on the HIP path yet "
                                       "(never enabled by the reference's configs; SURVEY 8f-4)")
         if spatial_dims not in (2, 3):
             raise ValueError("spatial_dims must be 2 or 3")
@@ -247,6 +259,10 @@ class DiffusionModelUNet(HipModule):
         self.num_head_channels = nhc = tuple(num_head_channels)
         self.with_conditioning = False
         self.num_class_embeds = num_class_embeds
+        self.resblock_updown = bool(resblock_updown)
+        # Activation checkpointing per ResnetBlock / AttentionBlock (BASELINE config 5; the reference has it in AutoencoderKL only,
+        # AEKL:761-762): not a constructor keyword of the reference class, so it is an attribute -- `net.use_checkpointing = True`
+        self.use_checkpointing = False
         self.groups, self.eps = norm_num_groups, norm_eps
         L = len(ch)
         self._k = [_axis3(kernel_sizes[i], sd, 1) for i in range(L)]
@@ -283,7 +299,10 @@ class DiffusionModelUNet(HipModule):
                 if att[i]:
                     attn(f"down_blocks.{i}.attentions.{j}", out_c)
             if i != L - 1:
-                spec.conv(f"down_blocks.{i}.downsampler.op.conv", out_c, out_c, kernel_sizes[i + 1])
+                if resblock_updown:  # ResnetBlock(down=True): avg-pool resampler, no parameters of its own (UNet:752-765)
+                    resnet(f"down_blocks.{i}.downsampler", out_c, out_c)
+                else:
+                    spec.conv(f"down_blocks.{i}.downsampler.op.conv", out_c, out_c, kernel_sizes[i + 1])
         resnet("middle_block.resnet_1", ch[-1], ch[-1])
         attn("middle_block.attention", ch[-1])
         resnet("middle_block.resnet_2", ch[-1], ch[-1])
@@ -299,7 +318,10 @@ class DiffusionModelUNet(HipModule):
                 if ratt[i]:
                     attn(f"up_blocks.{i}.attentions.{j}", out_c)
             if i != L - 1:
-                spec.conv(f"up_blocks.{i}.upsampler.conv.conv", out_c, out_c, 3)
+                if resblock_updown:  # ResnetBlock(up=True) (UNet:1229-1241)
+                    resnet(f"up_blocks.{i}.upsampler", out_c, out_c)
+                else:
+                    spec.conv(f"up_blocks.{i}.upsampler.conv.conv", out_c, out_c, 3)
         spec.norm("out.0", ch[0])
         spec.conv("out.2.conv", ch[0], out_channels, 3, zero=True)
         if num_class_embeds is not None:  # nn.Embedding(num_class_embeds, time_embed_dim): N(0, 1) rows (UNet:1837-1839)
@@ -311,7 +333,14 @@ class DiffusionModelUNet(HipModule):
         for a in self._attns:
             groups.append([f"{a}.to_{t}.weight" for t in "qkv"])
             groups.append([f"{a}.to_{t}.bias" for t in "qkv"])
-        self._init_plumbing(spec, groups)
+        # Gradient-completion order (data-parallel overlap, trainer._ArenaTrainer): the backward pass ends with the finest levels of
+        # the down path, conv_in and the time-embedding MLP (which also produces every time_emb_proj / conv1-bias gradient).  Those
+        # tensors form the arena's late prefix; everything else (>= 95 % of the bytes: the wide, coarse levels) is final when the
+        # backward reaches the cut mark _run records after down level `_cut_level`.
+        self._cut_level = max(0, L // 2 - 1)
+        late_pre = tuple(f"down_blocks.{i}." for i in range(self._cut_level + 1)) + ("conv_in.", "time_embed.", "class_embedding.")
+        late = [n for n, _, _ in spec.order if n.startswith(late_pre) or ".time_emb_proj." in n or n.endswith(".conv1.conv.bias")]
+        self._init_plumbing(spec, groups, late)
         self._temb_off = {}
         off = 0
         for name, _, cout in self._resnets:
@@ -320,26 +349,26 @@ class DiffusionModelUNet(HipModule):
         self._temb_total = off
 
     # ------------------------------------------------------------------------------------------ engine forward
-    def _resnet(self, c, x, name, temb_all, d_temb_all, out=None):
-        """ResnetBlock.forward (UNet:674-701) as 2 stats passes + 3 fused convs.  out: where conv2 writes the block's result (the
-        first channels of the next skip-concat buffer)."""
+    def _resnet(self, c, x, name, temb_all, d_temb_all, out=None, mode=None, stride=None, kernel=None):
+        """ResnetBlock.forward (UNet:674-701) with this block's columns of the all-resnets time-embedding projection."""
         cout = c.p(name + ".conv1.conv.weight").shape[0]
         off = self._temb_off[name]
-        k3, s1, p1 = (1,) * (3 - self.spatial_dims) + (3,) * self.spatial_dims, (1, 1, 1), (0,) * (3 - self.spatial_dims) + (1,) * self.spatial_dims
-        n1 = E.gn(c, x, name + ".norm1", self.groups, self.eps)
-        h = E.conv(c, x, name + ".conv1.conv", k3, s1, p1, norm=n1, silu=True, addvec=temb_all[:, off:off + cout],
-                   d_addvec=d_temb_all[:, off:off + cout] if d_temb_all is not None else None)
-        n2 = E.gn(c, h, name + ".norm2", self.groups, self.eps)
-        if name + ".skip_connection.conv.weight" in c.arena.offsets:
-            xs = E.conv(c, x, name + ".skip_connection.conv", (1, 1, 1), s1, (0, 0, 0), bias_grad_like=name + ".conv2.conv")
-        else:
-            xs = x
-        return E.conv(c, h, name + ".conv2.conv", k3, s1, p1, norm=n2, silu=True, res=xs, out=out)
+
+        def run(cc, xx):
+            return E.resnet(cc, xx, name, self.spatial_dims, self.groups, self.eps, temb_all[:, off:off + cout],
+                            d_temb_all[:, off:off + cout] if d_temb_all is not None else None, mode=mode, stride=stride, kernel=kernel,
+                            out=out if cc is c or cc.tape is None else None)  # the recomputation writes a buffer of its own
+
+        return E.checkpoint(c, run, x) if self.use_checkpointing else run(c, x)
+
+    def _attention(self, c, x, name, heads):
+        run = lambda cc, xx: E.attention(cc, xx, name, self.groups, self.eps, heads)
+        return E.checkpoint(c, run, x) if self.use_checkpointing else run(c, x)
 
     def _heads(self, ch, nhc):
         return ch // nhc if nhc is not None else 1
 
-    def _run(self, c: E.Ctx, x_cl, timesteps, need_dx, class_labels=None):
+    def _run(self, c: E.Ctx, x_cl, timesteps, need_dx, class_labels=None, down_res=None, mid_res=None):
         ch, L, sd = self.block_out_channels, len(self.block_out_channels), self.spatial_dims
         a = c.arena
         dev = x_cl.device
@@ -358,7 +387,7 @@ class DiffusionModelUNet(HipModule):
         temb_all, bwd3 = E.linear_f32(se, a.span(wn).view(T, self.temb_dim), a.span(bn), a.span(wn, a.grad).view(T, self.temb_dim),
                                       a.span(bn, a.grad))
         ops.add_f32_(temb_all, a.span([r[0] + ".conv1.conv.bias" for r in self._resnets]))  # fold conv1 biases in
-        d_temb_all = torch.zeros_like(temb_all) if grad else None  # conv1 wgrads accumulate their dy column sums here
+        d_temb_all = ops.zero_f32_2d_(torch.empty_like(temb_all)) if grad else None  # conv1 wgrads accumulate their dy column sums here
         if grad:
             def bwd_emb():
                 # d_temb_all holds every conv1's per-image dy column sums: their batch sums are the conv1 bias gradients
@@ -379,20 +408,33 @@ class DiffusionModelUNet(HipModule):
             for j in range(self.num_res_blocks[i]):
                 h = self._resnet(c, h, f"down_blocks.{i}.resnets.{j}", temb_all, d_temb_all)
                 if self.attention_levels[i]:
-                    h = E.attention(c, h, f"down_blocks.{i}.attentions.{j}", self.groups, self.eps, self._heads(ch[i], self.num_head_channels[i]))
+                    h = self._attention(c, h, f"down_blocks.{i}.attentions.{j}", self._heads(ch[i], self.num_head_channels[i]))
                 skips.append(h)
             if i != L - 1:
-                h = E.conv(c, h, f"down_blocks.{i}.downsampler.op.conv", self._k[i + 1], self._s[i + 1], self._p[i + 1])
+                if self.resblock_updown:
+                    h = self._resnet(c, h, f"down_blocks.{i}.downsampler", temb_all, d_temb_all, mode="down", stride=self._s[i + 1],
+                                     kernel=self._k[i + 1])
+                else:
+                    h = E.conv(c, h, f"down_blocks.{i}.downsampler.op.conv", self._k[i + 1], self._s[i + 1], self._p[i + 1])
                 skips.append(h)
+            if i == self._cut_level and grad:
+                c.tape.record(E.CUT)  # backward order: everything recorded after this point has run when the tape gets here
+        if down_res is not None:  # ControlNet residuals: one per skip, added before the up path reads them (UNet:1995-2003)
+            if len(down_res) != len(skips):
+                raise ValueError(f"down_block_additional_residuals must hold {len(skips)} tensors, got {len(down_res)}")
+            skips = [E.add(c, sk, r, b_needs_grad=False) for sk, r in zip(skips, down_res)]
         h = self._resnet(c, h, "middle_block.resnet_1", temb_all, d_temb_all)
-        h = E.attention(c, h, "middle_block.attention", self.groups, self.eps, self._heads(ch[-1], self.num_head_channels[-1]))
+        h = self._attention(c, h, "middle_block.attention", self._heads(ch[-1], self.num_head_channels[-1]))
         # Whatever feeds a skip concatenation (UNet:1263, 1377, 1504) is written by its producing conv straight into the first
         # channels of the concat buffer: only the skip half is copied, and in backward d(producer output) is a view of d(cat).
         def cat_buffer(ca):
             return E.concat_buffer(skips[-1].shape, ca, skips[-1].shape[-1], dev)
 
         pending, view = cat_buffer(ch[-1])
-        h = self._resnet(c, h, "middle_block.resnet_2", temb_all, d_temb_all, out=view)
+        h = self._resnet(c, h, "middle_block.resnet_2", temb_all, d_temb_all, out=None if mid_res is not None else view)
+        if mid_res is not None:  # UNet:2008-2010
+            h = E.add(c, h, mid_res, b_needs_grad=False)
+            pending, view = None, None
         rch, rnrb = list(reversed(ch)), list(reversed(self.num_res_blocks))
         ratt, rnhc = list(reversed(self.attention_levels)), list(reversed(self.num_head_channels))
         rs, rp = list(reversed(self._s)), list(reversed(self._p))
@@ -405,8 +447,11 @@ class DiffusionModelUNet(HipModule):
                     pending, view = cat_buffer(rch[i])
                 h = self._resnet(c, h, f"up_blocks.{i}.resnets.{j}", temb_all, d_temb_all, out=view)
                 if ratt[i]:
-                    h = E.attention(c, h, f"up_blocks.{i}.attentions.{j}", self.groups, self.eps, self._heads(rch[i], rnhc[i]))
-            if i != L - 1:  # Upsample.forward (UNet:569-588): nearest x stride, then k3 conv with the LEVEL's padding
+                    h = self._attention(c, h, f"up_blocks.{i}.attentions.{j}", self._heads(rch[i], rnhc[i]))
+            if i != L - 1 and self.resblock_updown:
+                pending, view = cat_buffer(rch[i])
+                h = self._resnet(c, h, f"up_blocks.{i}.upsampler", temb_all, d_temb_all, out=view, mode="up", stride=rs[i])
+            elif i != L - 1:  # Upsample.forward (UNet:569-588): nearest x stride, then k3 conv with the LEVEL's padding
                 h = E.upsample(c, h, rs[i])
                 pending, view = cat_buffer(rch[i])
                 h = E.conv(c, h, f"up_blocks.{i}.upsampler.conv.conv", k3, (1, 1, 1), rp[i], out=view)
@@ -419,8 +464,6 @@ class DiffusionModelUNet(HipModule):
                 mid_block_additional_residual=None):
         if context is not None:
             raise ValueError("model should have with_conditioning = True if context is provided")
-        if down_block_additional_residuals is not None or mid_block_additional_residual is not None:
-            raise NotImplementedError("ControlNet residual inputs are not on the HIP path yet")
         if timesteps.ndim != 1:
             raise ValueError("Timesteps should be a 1d-array")
         if x.shape[1] != self.in_channels:
@@ -436,10 +479,16 @@ class DiffusionModelUNet(HipModule):
             if class_labels.shape != timesteps.shape or int(class_labels.min()) < 0 or int(class_labels.max()) >= self.num_class_embeds:
                 raise IndexError("class_labels must hold one index in [0, num_class_embeds) per sample")  # nn.Embedding's range check
 
+        # ControlNet residuals (UNet:1995-2010) enter as constants: a ControlNet is trained through its own graph, not through the
+        # U-Net's skip additions, so no gradient is returned for them
+        to_cl = lambda r: ops.to_channels_last(r.detach().to(x.device).contiguous().float())
+        down_res = [to_cl(r) for r in down_block_additional_residuals] if down_block_additional_residuals is not None else None
+        mid_res = to_cl(mid_block_additional_residual) if mid_block_additional_residual is not None else None
+
         def runner(c, xin, need_dx):
             x_cl = ops.to_channels_last(xin.contiguous().float())
-            y = self._run(c, x_cl, timesteps, need_dx, class_labels)
+            y = self._run(c, x_cl, timesteps, need_dx, class_labels, down_res, mid_res)
             return (y,), {"x_cl": x_cl}
 
         grad_enabled = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))
-        return _NetFn.apply(self, runner, 1, grad_enabled, x, *self.parameters())
+        return _NetFn.apply(self, runner, 1, grad_enabled, x, None, *self.parameters())

@@ -45,6 +45,31 @@ UNET_CASES = {
                     attention_levels=(False, False), num_head_channels=(0, 16), norm_num_groups=8, resblock_updown=True,
                     strides=[[1, 1], [2, 2]], kernel_sizes=[[3, 3], [2, 2]], paddings=[[1, 1], [0, 0]]),
         shape=(2, 1, 16, 16), timesteps=(10, 20)),
+    # ---- the BASELINE configs on their EXACT model kwargs, at sizes the reference finishes in seconds on CPU ----
+    # C2 / C4: pixel-space 3D DDPM net, (32,64,128,256), 2 res-blocks, attention at the coarsest level with heads of 64
+    "unet_c4": dict(
+        kwargs=dict(spatial_dims=3, in_channels=1, out_channels=1, num_res_blocks=2, num_channels=(32, 64, 128, 256),
+                    attention_levels=(False, False, False, True), num_head_channels=(0, 0, 0, 64), norm_num_groups=32,
+                    strides=_iso(3, 4), kernel_sizes=[[3] * 3] * 4, paddings=[[1] * 3] * 4),
+        shape=(2, 1, 32, 32, 32), timesteps=(100, 800)),
+    # the same net on non-power-of-two, anisotropic extents (every level ragged against the 4x8x8 conv tiles: 24x40x48 -> 3x5x6)
+    "unet_c4_np2": dict(
+        kwargs=dict(spatial_dims=3, in_channels=1, out_channels=1, num_res_blocks=2, num_channels=(32, 64, 128, 256),
+                    attention_levels=(False, False, False, True), num_head_channels=(0, 0, 0, 64), norm_num_groups=32,
+                    strides=_iso(3, 4), kernel_sizes=[[3] * 3] * 4, paddings=[[1] * 3] * 4),
+        shape=(1, 1, 24, 40, 48), timesteps=(611,)),
+    # C3b: the ONLY latent UNet the reference's planner emits (CFG:876-902): [256,512,768], ONE head of 512 / 768
+    "unet_c3b": dict(
+        kwargs=dict(spatial_dims=3, in_channels=8, out_channels=8, num_res_blocks=2, num_channels=(256, 512, 768),
+                    attention_levels=(False, True, True), num_head_channels=(0, 512, 768), norm_num_groups=32,
+                    strides=_iso(3, 3), kernel_sizes=[[3] * 3] * 3, paddings=[[1] * 3] * 3),
+        shape=(1, 8, 8, 8, 8), timesteps=(333,)),
+    # C5: C3b net with one label channel concatenated to the latents (in_channels = 8 + 1), non-power-of-two latent extent
+    "unet_c5": dict(
+        kwargs=dict(spatial_dims=3, in_channels=9, out_channels=8, num_res_blocks=2, num_channels=(256, 512, 768),
+                    attention_levels=(False, True, True), num_head_channels=(0, 512, 768), norm_num_groups=32,
+                    strides=_iso(3, 3), kernel_sizes=[[3] * 3] * 3, paddings=[[1] * 3] * 3),
+        shape=(1, 9, 12, 12, 12), timesteps=(42,)),
 }
 
 _C3A_DOWN = [[[1] * 3, [3] * 3, [1] * 3], [[2] * 3, [3] * 3, [1] * 3], [[2] * 3, [3] * 3, [1] * 3]]

@@ -186,6 +186,11 @@ def main():
     ru = _load("_ref_unet", "diffusion_model_unet_with_strides.py")
     ra = _load("_ref_aekl", "autoencoderkl_with_strides.py")
     print("golden vectors ->", OUT)
+    only = sys.argv[1:]  # optional: regenerate just the named UNet cases (new cases leave the committed fixtures untouched)
+    if only:
+        for name in only:
+            unet_case(ru, name)
+        return
     known_answers(ru)
     for name in cases.UNET_CASES:
         unet_case(ru, name)

@@ -1,0 +1,155 @@
+"""The BASELINE.json configs at their FULL sizes.  The metric's own workload (C4, 128^3 x 1) and C2 (96^3) are
+compared with the CPU oracle directly (one oracle step at 128^3 takes ~20 s on the GPU box's 16 host cores); the larger latent
+nets through size-independent properties:
+  * finite loss and finite gradients on every trainable parameter slot;
+  * reproducibility: two runs of the same step on the same inputs agree to fp32 summation-order noise (rel-L2 <= 1e-5 on the
+    gradient arena; the bias / GroupNorm-parameter / 1x1-weight-gradient reductions and the scalar loss finish with fp32
+    atomics, so they are order-dependent in the last bits, like torch's default kernels; everything bf16 is bit-stable);
+  * batch consistency: a batch of IDENTICAL samples gives each sample the batch-1 prediction up to bf16 rounding flips
+    (rel-L2 <= 2e-3: the plan picks register-blocking variants and attention split factors by workgroup count, which depends
+    on the batch, so fp32 partial sums are associated differently; bit-exact where the plans coincide, e.g. C4 at 64^3 in
+    test_unet_gpu.py::test_batch_consistency_at_realistic_size);
+  * linearity of the backward pass in the output gradient is covered by the optimizer-trajectory goldens at small size.
+The same kwargs are compared against the reference's golden vectors and the oracle at small sizes in test_unet_gpu.py
+(`unet_c4`, `unet_c4_np2`, `unet_c3b`, `unet_c5`) and test_aekl_gpu.py (`aekl_c3a`)."""
+import math
+
+import pytest
+import torch
+
+from oracle import cases
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda")
+
+
+def _net(kwargs, seed):
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    torch.manual_seed(seed)
+    net = DiffusionModelUNet(**kwargs)
+    for p in net.parameters():  # un-zero the zero_module'd convs: otherwise half the backward multiplies zeros
+        if float(p.detach().abs().max()) == 0:
+            torch.nn.init.normal_(p, std=0.02)
+    return net.to(dev)
+
+
+def _oracle_net(kwargs, net):
+    """The CPU restatement with the HIP net's current weights."""
+    from oracle import nets
+    torch.set_num_threads(16)
+    ref = nets.DiffusionModelUNet(**kwargs)
+    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    return ref
+
+
+def _volume(shape, seed):
+    import bench
+    return bench.synthetic_volume(shape, seed, dev)
+
+
+def _ddpm_properties(kwargs, shape, tag, identical_batch):
+    from medical_image_generation_amd.trainer import DDPMTrainer
+    net = _net(kwargs, 11)
+    tr = DDPMTrainer(net, lr=2e-5)
+    n = shape[0]
+    g = torch.Generator(device=dev).manual_seed(5)
+    if identical_batch and n > 1:
+        x0 = _volume((1,) + shape[1:], 7).repeat(n, *([1] * (len(shape) - 1)))
+        noise = torch.randn((1,) + shape[1:], device=dev, generator=g).repeat(n, *([1] * (len(shape) - 1)))
+        t = torch.full((n,), 417, dtype=torch.int64, device=dev)
+    else:
+        x0 = _volume(shape, 7)
+        noise = torch.randn(shape, device=dev, generator=g)
+        t = torch.randint(0, 1000, (n,), device=dev, generator=g)
+    nt = tr.arena.n_trainable
+    tr.forward_backward(x0, noise, t)
+    l1, g1 = float(tr.loss), tr.arena.grad[:nt].clone()
+    tr.forward_backward(x0, noise, t)
+    l2, g2 = float(tr.loss), tr.arena.grad[:nt].clone()
+    assert math.isfinite(l1) and l1 > 0 and bool(torch.isfinite(g1).all()), f"{tag}: non-finite loss / gradients"
+    assert float(g1.abs().max()) > 0
+    rep = float((g1 - g2).norm() / g1.norm())
+    assert abs(l1 - l2) <= 2e-6 * abs(l1) and rep <= 1e-5, f"{tag}: two identical steps differ (loss {l1} / {l2}, gradient rel-L2 {rep:.2e})"
+    if identical_batch and n > 1:
+        with torch.no_grad():
+            y = net(x0, t)
+            y1 = net(x0[:1], t[:1])
+        assert torch.equal(y[0], y[1]), f"{tag}: two identical samples of ONE batch differ"
+        # batch 2 and batch 1 may run different register-blocking variants / attention splits (the plan goes by workgroup count), so
+        # they are two bf16 evaluations of the same function: each must sit within the bf16 budget of the fp32 oracle
+        ref = _oracle_net(kwargs, net)
+        with torch.no_grad():
+            yr = ref(x0[:1].cpu(), t[:1].cpu())
+        e2, e1 = float((y[:1].cpu() - yr).norm() / yr.norm()), float((y1.cpu() - yr).norm() / yr.norm())
+        print(f"\n[{tag}] prediction vs fp32 oracle at full size: batch-{n} {e2:.3e}, batch-1 {e1:.3e}")
+        assert e2 <= 3e-2 and e1 <= 3e-2
+    print(f"\n[{tag}] loss {l1:.5f}, |grad| {float(g1.norm()):.4e}, finite; run-to-run gradient rel-L2 {rep:.1e}")
+    return tr
+
+
+def test_c4_full_size():
+    """BASELINE configs[3] / the metric's workload: C4 net, 128^3 x batch 1 -- properties, then the SAME step on the CPU oracle
+    (q-sample -> UNet -> MSE -> backward, fp32): loss within 1 %, global parameter-gradient rel-L2 <= 4e-2 (the small-size budget)."""
+    from oracle import step
+    kwargs, shape = cases.UNET_CASES["unet_c4"]["kwargs"], (1, 1, 128, 128, 128)
+    tr = _ddpm_properties(kwargs, shape, "C4 128^3 b1", False)
+    g = torch.Generator(device=dev).manual_seed(5)  # the inputs _ddpm_properties drew
+    x0 = _volume(shape, 7)
+    noise = torch.randn(shape, device=dev, generator=g)
+    t = torch.randint(0, 1000, (1,), device=dev, generator=g)
+    tr.forward_backward(x0, noise, t)
+    ref = _oracle_net(kwargs, tr.model)
+    loss_ref, _ = step.ddpm_loss(ref, step.DDPMSchedule(), x0.cpu(), noise.cpu(), t.cpu())
+    loss_ref.backward()
+    names = [n for n, p in ref.named_parameters() if p.grad is not None]
+    g_ref = torch.cat([dict(ref.named_parameters())[n].grad.flatten() for n in names])
+    g_hip = torch.cat([tr.arena.gview(n).cpu().flatten() for n in names])
+    e = float((g_hip - g_ref).norm() / g_ref.norm())
+    print(f"\n[C4 128^3 b1 vs fp32 oracle, full size] loss {float(tr.loss):.6f} vs {float(loss_ref):.6f}; global gradient rel-L2 {e:.3e}")
+    assert abs(float(tr.loss) - float(loss_ref)) <= 1e-2 * float(loss_ref) and e <= 4e-2
+
+
+def test_c2_full_size():
+    """BASELINE configs[1]: the same net at 96^3 x batch 2 (non-power-of-two extents at every level: 96 -> 48 -> 24 -> 12)."""
+    _ddpm_properties(cases.UNET_CASES["unet_c4"]["kwargs"], (2, 1, 96, 96, 96), "C2 96^3 b2", True)
+
+
+def test_c3b_full_size():
+    """BASELINE configs[2], second half: the planner's latent UNet [256,512,768] on 4 x 8 x 32^3 latents."""
+    _ddpm_properties(cases.UNET_CASES["unet_c3b"]["kwargs"], (4, 8, 32, 32, 32), "C3b 32^3 latents b4", False)
+
+
+def test_c5_full_size():
+    """BASELINE configs[4]: label-channel-conditioned latent UNet on 9 x 40^3 latents (160^3 patch), batch 1 per GPU."""
+    _ddpm_properties(cases.UNET_CASES["unet_c5"]["kwargs"], (1, 9, 40, 40, 40), "C5 40^3 latents b1", False)
+
+
+def test_c3a_full_size():
+    """BASELINE configs[2], first half: AutoencoderKL (reference-generated kwargs) at 128^3 x batch 2 -> 8 x 32^3 latents."""
+    from medical_image_generation_amd.autoencoderkl import AutoencoderKL
+    from medical_image_generation_amd.trainer import AETrainer
+    torch.manual_seed(13)
+    net = AutoencoderKL(**cases.AEKL_CASES["aekl_c3a"]["kwargs"]).to(dev)
+    tr = AETrainer(net)
+    x1 = _volume((1, 1, 128, 128, 128), 9)
+    x = x1.repeat(2, 1, 1, 1, 1)
+    g = torch.Generator(device=dev).manual_seed(3)
+    eps = torch.randn((1, 8, 32, 32, 32), device=dev, generator=g).repeat(2, 1, 1, 1, 1)
+    nt = tr.arena.n_trainable
+    tr.forward_backward(x, eps)
+    l1, g1 = float(tr.loss), tr.arena.grad[:nt].clone()
+    tr.forward_backward(x, eps)
+    l2, g2 = float(tr.loss), tr.arena.grad[:nt].clone()
+    assert math.isfinite(l1) and bool(torch.isfinite(g1).all()) and float(g1.abs().max()) > 0
+    rep = float((g1 - g2).norm() / g1.norm())
+    assert abs(l1 - l2) <= 2e-6 * abs(l1) and rep <= 1e-5, f"C3a: two identical steps differ (loss {l1} / {l2}, gradient rel-L2 {rep:.2e})"
+    with torch.no_grad():
+        mu, sigma = net.encode(x)
+        mu1, sigma1 = net.encode(x1)
+        rec, rec1 = net.decode(mu), net.decode(mu1)
+    assert mu.shape == (2, 8, 32, 32, 32) and rec.shape == x.shape
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for i in range(2):
+        assert rel(mu[i:i + 1], mu1) <= 2e-3 and rel(sigma[i:i + 1], sigma1) <= 2e-3 and rel(rec[i:i + 1], rec1) <= 5e-3
+    assert torch.equal(mu[0], mu[1]) and torch.equal(rec[0], rec[1])  # identical samples of one batch: bit-identical
+    print(f"\n[C3a 128^3 b2] loss {l1:.5f}, |grad| {float(g1.norm()):.4e}, finite, batch-consistent; run-to-run gradient rel-L2 {rep:.1e}")

@@ -243,6 +243,41 @@ def test_conv_residual_at_size(ops, c):
         assert torch.equal(y, want), f"residual epilogue differs (sums={with_sums}): {int((y != want).sum())} elements"
 
 
+@pytest.mark.parametrize("c", [32, 64])
+def test_conv27_at_size_vs_fp32_reference(ops, c):
+    """The MFMA loops of k_conv27 read their fragments with inline-asm `ds_read_b128` consumed behind hand-counted `lgkmcnt` waits (the
+    idiom class of the asynchronous-load bug fixed in round 1).  Evidence instead of argument: both register-blocking variants
+    (c = 32: <1,.>, c = 64: <2,.>), forward (with and without the GroupNorm-sum epilogue) AND data gradient, against fp32
+    F.conv3d on the CPU at 2 x 64^3 -- 2048 tiles per image pair, HBM latency real, every workgroup persistent over many tiles."""
+    n, d = 2, 64
+    g = torch.Generator().manual_seed(100 + c)
+    x = torch.randn(n, c, d, d, d, generator=g).bfloat16().float()
+    w = (torch.randn(c, c, 3, 3, 3, generator=g) / math.sqrt(27 * c))
+    bias = torch.randn(c, generator=g)
+    gy = torch.randn(n, c, d, d, d, generator=g).bfloat16().float()
+    torch.set_num_threads(16)
+    wb = w.bfloat16().float()  # the kernel multiplies bf16-rounded weights
+    y_ref = F.conv3d(x, wb, bias, padding=1)
+    dx_ref = F.conv_transpose3d(gy, wb, None, padding=1)  # data gradient of a stride-1 conv
+    plan = ops.ConvPlan(n, (d, d, d), c, c, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    plan.pack(w.to(dev))
+    xc, gc = cl(x), cl(gy)
+    y0 = plan.fwd(xc, addvec=bias.to(dev))
+    y1, sums = plan.fwd(xc, addvec=bias.to(dev), want_sums=True)
+    assert torch.equal(y0, y1)
+    # bf16 output rounding is the only error source: inputs and weights are exactly representable, accumulation is fp32
+    check(cf(y0), y_ref, 4e-3, f"conv27 fwd c={c} @2x64^3")
+    assert float((cf(y0) - y_ref).abs().max()) <= 2.0 ** -7 * float(y_ref.abs().max())  # every element within bf16 rounding of fp32
+    dx = plan.dgrad(gc)
+    check(cf(dx), dx_ref, 4e-3, f"conv27 dgrad c={c} @2x64^3")
+    assert float((cf(dx) - dx_ref).abs().max()) <= 2.0 ** -7 * float(dx_ref.abs().max())
+    if sums is not None:  # the emitted per-channel sums equal the sums of the stored tensor
+        got = sums.partial.view(n, c, -1, 2).sum(2).cpu()
+        yf = y0.float().cpu()
+        check(got[..., 0], yf.sum(dim=(1, 2, 3)), 1e-3, "emitted channel sums")
+        check(got[..., 1], (yf * yf).sum(dim=(1, 2, 3)), 1e-3, "emitted channel sums of squares")
+
+
 def test_conv_fused_prologue_epilogue(ops):
     """GroupNorm-affine + SiLU prologue, per-sample add vector (bias + temb) and residual in the epilogue."""
     n, cin, cout, dims = 2, 64, 32, (4, 8, 8)
@@ -278,11 +313,11 @@ def test_train_glue(ops):
     out = torch.empty((n, *dims, c), dtype=torch.bfloat16, device=dev)
     sa, so = acp.sqrt().to(dev), (1 - acp).sqrt().to(dev)
     x0d, nd, td = x0.to(dev), noise.to(dev), t.to(dev)  # keep alive: calls are asynchronous
-    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(out), None, n, c, v)
+    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(out), None, n, c, v, 1000)
     ref = acp[t].sqrt().view(n, 1, 1, 1, 1) * x0 + (1 - acp[t]).sqrt().view(n, 1, 1, 1, 1) * noise
     check(cf(out), ref, 1e-2, "qsample")
     vel = torch.empty_like(x0d)  # v-prediction target (scheduler.get_velocity, T-LDM:163-165)
-    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(out), ptr(vel), n, c, v)
+    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(out), ptr(vel), n, c, v, 1000)
     check(vel.cpu(), acp[t].sqrt().view(n, 1, 1, 1, 1) * noise - (1 - acp[t]).sqrt().view(n, 1, 1, 1, 1) * x0, 1e-6, "velocity target")
     pred = rnd(n, c, *dims, seed=2)
     pr = pred.clone().requires_grad_(True)
@@ -311,6 +346,9 @@ def test_adam_matches_torch(ops, decoupled, wd):
         opt.step()
         gd = g.clone().to(dev)
         call("mi_sumsq_f32", ptr(gd), n, ptr(sumsq), 0)
-        call("mi_adam_step", ptr(p), ptr(gd), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled, ptr(sumsq), 1.0, ptr(step))
+        # the gradient buffer holds 4x the gradient and grad_scale = 1/4 undoes it (the data-parallel SUM all-reduce over 4 ranks)
+        gd4 = gd * 4
+        call("mi_sumsq_f32", ptr(gd4), n, ptr(sumsq), 0)
+        call("mi_adam_step", ptr(p), ptr(gd4), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled, ptr(sumsq), 1.0, 0.25, ptr(step))
     assert float(step) == 3.0
     check(p.cpu(), pr.detach(), 1e-5, "adam params")

@@ -138,3 +138,187 @@ def test_v_prediction_step_matches_oracle():
     assert err <= 4e-2
     with pytest.raises(ValueError):
         DDPMSchedule(prediction_type="sample")
+
+
+def test_gradient_accumulation_matches_oracle():
+    """grad_accumulate_step = 2 (train_ldm.py:173-180): the gradients of two micro-batches are SUMMED (loss not divided), clipped and
+    applied once; the optimizer does not move on the first micro-step."""
+    from medical_image_generation_amd.trainer import DDPMTrainer
+    c, ref, net = _nets("unet3d")
+    sd0 = {k: v.clone() for k, v in ref.state_dict().items()}
+    tr = DDPMTrainer(net, lr=cases.STEP_LR, optimizer="AdamW", max_grad_norm=1.0, grad_accumulate_step=2)
+    opt = torch.optim.AdamW(ref.parameters(), lr=cases.STEP_LR)
+    sched = step.DDPMSchedule()
+    t = torch.tensor(c["timesteps"])
+    x = [synth.ellipsoid_volume(S, f"x0_{k}", c["shape"]) for k in range(2)]
+    nz = [synth.tensor(S, f"noise{k}", c["shape"]) for k in range(2)]
+    losses_ref = []
+    for k in range(2):  # reference loop body: backward every micro-step, clip + step + zero_grad on the boundary
+        loss, _ = step.ddpm_loss(ref, sched, x[k], nz[k], (t + 11 * k) % 1000)
+        loss.backward()
+        losses_ref.append(float(loss))
+    g_ref = torch.cat([p.grad.flatten() for n, p in ref.named_parameters() if p.grad is not None])
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+    opt.step()
+    before = tr.arena.data.clone()
+    l0 = float(tr.step(x[0].cuda(), nz[0].cuda(), t.cuda()))
+    assert torch.equal(tr.arena.data, before) and float(tr.step_count) == 0.0  # no optimizer step on a non-boundary micro-step
+    l1 = float(tr.step(x[1].cuda(), nz[1].cuda(), ((t + 11) % 1000).cuda()))
+    assert float(tr.step_count) == 1.0 and tr._micro == 0
+    names = [n for n, p in ref.named_parameters() if p.grad is not None]
+    g_hip = torch.cat([tr.arena.gview(n).cpu().flatten() for n in names])  # arena.grad holds the folded sum after the boundary
+    e_g = float((g_hip - g_ref).norm() / g_ref.norm())
+    upd_ref = torch.cat([(ref.state_dict()[n] - sd0[n]).flatten() for n in names])
+    upd_hip = torch.cat([(net.state_dict()[n].cpu() - sd0[n]).flatten() for n in names])
+    cos = float(torch.dot(upd_ref, upd_hip) / (upd_ref.norm() * upd_hip.norm()))
+    print(f"\n[accumulate 2] losses {l0:.5f} {l1:.5f} vs {losses_ref}; summed-gradient rel-L2 {e_g:.3e}; update cosine {cos:.4f}")
+    assert abs(l0 - losses_ref[0]) <= 1e-2 * losses_ref[0] and abs(l1 - losses_ref[1]) <= 1e-2 * losses_ref[1]
+    assert e_g <= 4e-2 and cos >= 0.9
+    # last_in_epoch forces the boundary (T-LDM:173: `(step + 1) == len(train_loader)`)
+    tr.step(x[0].cuda(), nz[0].cuda(), t.cuda(), last_in_epoch=True)
+    assert float(tr.step_count) == 2.0 and tr._micro == 0
+
+
+def test_backward_cut_is_sound_and_split_graphs_agree():
+    """Data-parallel overlap rests on one claim: when the tape reaches the model's cut mark, every gradient of the arena's early
+    segment [n_late, n_trainable) is FINAL.  Check it on the real net: snapshot the early segment at the cut, finish the backward,
+    compare bit for bit.  Then the two-graph capture (cut between the graphs, as world > 1 runs it) must reproduce the one-graph
+    step: same loss, same parameters after two steps (up to the fp32-atomic summation-order noise of the bias reductions)."""
+    import bench
+    from medical_image_generation_amd.trainer import DDPMTrainer
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+
+    def make():
+        torch.manual_seed(5)
+        net = DiffusionModelUNet(**bench.C4)
+        for p in net.parameters():
+            if float(p.detach().abs().max()) == 0:
+                torch.nn.init.normal_(p, std=0.02)
+        return net.cuda()
+
+    d = 32
+    x0 = bench.synthetic_volume((2, 1, d, d, d), 3, torch.device("cuda"))
+    g = torch.Generator(device="cuda").manual_seed(1)
+    noise = torch.randn((2, 1, d, d, d), device="cuda", generator=g)
+    t = torch.tensor([100, 900], device="cuda")
+    tr = DDPMTrainer(make(), lr=1e-4)
+    a = tr.arena
+    assert 0 < a.n_late < 0.1 * a.n_trainable  # the late prefix is a few percent of the bytes
+    snap = {}
+    tr.forward_backward(x0, noise, t, on_cut=lambda: snap.setdefault("early", a.grad[a.n_late:a.n_trainable].clone()))
+    early_final = a.grad[a.n_late:a.n_trainable]
+    assert float(snap["early"].abs().max()) > 0
+    assert torch.equal(snap["early"], early_final), "a gradient of the early segment changed after the cut mark"
+    late = a.grad[:a.n_late]
+    assert float(late.abs().max()) > 0  # ... and the late prefix does receive gradients afterwards
+    # one-graph vs two-graph capture
+    out = []
+    for split in (False, True):
+        trn = DDPMTrainer(make(), lr=1e-4)
+        trn._force_split = split
+        trn.capture(x0, noise, t)
+        assert (trn._g_fb2 is not None) == split
+        losses = [float(trn.step_graph()) for _ in range(2)]
+        out.append((losses, trn.arena.data[:trn.arena.n_trainable].clone()))
+    (l_a, p_a), (l_b, p_b) = out
+    e = float((p_a - p_b).norm() / p_a.norm())
+    print(f"\n[cut] n_late {a.n_late} of {a.n_trainable}; one-graph vs two-graph: losses {l_a} / {l_b}, parameter rel-L2 {e:.2e}")
+    assert all(abs(u - v) <= 1e-5 * abs(u) for u, v in zip(l_a, l_b)) and e <= 1e-6
+
+
+def test_graph_survives_other_shape_forward():
+    """a captured train step holds raw pointers into the PackBatch / conv plans / GroupNorm workspace; a forward at
+    another shape between train steps (validation, sampling) used to replace and free them.  capture -> sample at another batch
+    size -> replay must equal the eager trainer that never saw the detour."""
+    from medical_image_generation_amd.inferer import DDPMScheduler, DiffusionInferer
+    from medical_image_generation_amd.trainer import DDPMTrainer
+    c, _, net_a = _nets("unet3d")
+    _, _, net_b = _nets("unet3d")
+    x0 = synth.ellipsoid_volume(S, "x0", c["shape"]).cuda()
+    t = torch.tensor(c["timesteps"]).cuda()
+    tra, trb = DDPMTrainer(net_a, lr=cases.STEP_LR), DDPMTrainer(net_b, lr=cases.STEP_LR)
+    noise = [synth.tensor(S, f"noise{k}", c["shape"]).cuda() for k in range(3)]
+    tra.capture(x0, noise[0], t)
+    la = [float(tra.step_graph(x0, noise[0], t))]
+    lb = [float(trb.step(x0, noise[0], t))]
+    sch = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205)
+    sch.set_timesteps(4)
+    inf = DiffusionInferer(sch)
+    big = (5,) + tuple(c["shape"][1:3]) + (24, 24)  # another batch size AND another spatial extent: new plans, a larger workspace
+    inf.sample(torch.randn(big, device="cuda"), net_a, sch, verbose=False)
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    for k in (1, 2):
+        la.append(float(tra.step_graph(x0, noise[k], t)))
+        lb.append(float(trb.step(x0, noise[k], t)))
+    pa, pb = tra.arena.data[:tra.arena.n_trainable], trb.arena.data[:trb.arena.n_trainable]
+    e = float((pa - pb).norm() / pb.norm())
+    print(f"\n[graph lifetime] losses graph {la} eager {lb}; parameter rel-L2 {e:.2e}")
+    assert all(abs(u - v) <= 1e-4 * abs(v) for u, v in zip(la, lb)) and e <= 1e-5
+    with pytest.raises(ValueError):
+        tra.step(x0.double(), noise[0], t)           # wrong dtype is refused, not misread
+    with pytest.raises(ValueError):
+        tra.step(x0, noise[0], t.to(torch.int32))    # timesteps must be int64 [N]
+    tra.step(x0, noise[0], torch.tensor([-5, 5000], device="cuda"))  # out-of-range timesteps are clamped to the schedule
+    assert bool(torch.isfinite(tra.loss).all())
+
+
+def test_ldm_step_matches_oracle_composition():
+    """LDMTrainer = the 'vae' branch of train_ldm.py:154-180: no-grad AutoencoderKL.encode_stage_2_inputs -> * scale_factor ->
+    q-sample -> UNet -> MSE -> backward, against the same composition of the CPU restatements; scale_factor = 1/std(z) of the first
+    batch (train_ldm.py:110-112).  Also LatentDiffusionInferer.__call__ (the autograd-edge form of the same forward)."""
+    from medical_image_generation_amd.autoencoderkl import AutoencoderKL
+    from medical_image_generation_amd.inferer import DDPMScheduler, LatentDiffusionInferer
+    from medical_image_generation_amd.trainer import LDMTrainer
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    ca = cases.AEKL_CASES["aekl_c3a"]
+    ae_ref = nets.AutoencoderKL(**ca["kwargs"])
+    ae_sd = synth.state_dict({k: tuple(v.shape) for k, v in ae_ref.state_dict().items()}, S)
+    ae_ref.load_state_dict(ae_sd)
+    ae = AutoencoderKL(**ca["kwargs"])
+    ae.load_state_dict(ae_sd)
+    ae = ae.cuda()
+    ukw = dict(cases.UNET_CASES["unet_ldm"]["kwargs"])  # in/out 8 = the AE's latent channels
+    u_ref = nets.DiffusionModelUNet(**ukw)
+    u_sd = synth.state_dict({k: tuple(v.shape) for k, v in u_ref.state_dict().items()}, S + 1)
+    u_ref.load_state_dict(u_sd)
+    unet = DiffusionModelUNet(**ukw)
+    unet.load_state_dict(u_sd)
+    unet = unet.cuda()
+    x = synth.ellipsoid_volume(S, "x", (2, 1, 32, 32, 32))
+    with torch.no_grad():
+        mu, sigma = ae_ref.encode(x)
+    eps, noise = synth.tensor(S, "eps", mu.shape), synth.tensor(S, "lnoise", mu.shape)
+    t = torch.tensor([250, 750])
+    with torch.no_grad():
+        z = mu + eps * sigma
+    scale_ref = float(1 / torch.std(z))
+    sched = step.DDPMSchedule()
+    loss_ref, _ = step.ddpm_loss(u_ref, sched, z * scale_ref, noise, t)
+    loss_ref.backward()
+    tr = LDMTrainer(unet, ae, lr=1e-4)
+    with pytest.raises(RuntimeError):
+        tr.forward_backward(x.cuda(), eps.cuda(), noise.cuda(), t.cuda())  # scale factor not set yet
+    sf = tr.estimate_scale_factor(x.cuda(), eps.cuda())
+    assert abs(sf - scale_ref) <= 1e-2 * scale_ref
+    tr.forward_backward(x.cuda(), eps.cuda(), noise.cuda(), t.cuda())
+    names = [n for n, p in u_ref.named_parameters() if p.grad is not None]
+    g_ref = torch.cat([dict(u_ref.named_parameters())[n].grad.flatten() for n in names])
+    g_hip = torch.cat([tr.arena.gview(n).cpu().flatten() for n in names])
+    e = float((g_hip - g_ref).norm() / g_ref.norm())
+    print(f"\n[LDM step] scale_factor {sf:.5f} vs {scale_ref:.5f}; loss {float(tr.loss):.6f} vs {float(loss_ref):.6f}; gradient rel-L2 {e:.3e}")
+    assert abs(float(tr.loss) - float(loss_ref)) <= 1.5e-2 * float(loss_ref) and e <= 5e-2
+    assert float(tr.ae_arena.grad.abs().max()) == 0.0  # the autoencoder is frozen: nothing reached its gradient arena
+    # graph form: encoder + UNet step in one capture
+    tr.capture(x.cuda(), eps.cuda(), noise.cuda(), t.cuda())
+    lg = float(tr.step_graph())
+    assert abs(lg - float(loss_ref)) <= 1.5e-2 * float(loss_ref)
+    # the autograd-edge form of the same forward (generative.inferers.LatentDiffusionInferer.__call__)
+    inferer = LatentDiffusionInferer(DDPMScheduler(1000, "scaled_linear_beta", beta_start=0.0015, beta_end=0.0205), scale_factor=sf)
+    ae.sampling = lambda m, s: m + eps.cuda() * s  # pin the sampling noise
+    unet2 = DiffusionModelUNet(**ukw)
+    unet2.load_state_dict(u_sd)
+    pred = inferer(inputs=x.cuda(), autoencoder_model=ae, diffusion_model=unet2.cuda(), noise=noise.cuda(), timesteps=t.cuda())
+    loss2 = torch.nn.functional.mse_loss(pred.float(), noise.cuda())
+    assert abs(float(loss2) - float(loss_ref)) <= 1.5e-2 * float(loss_ref)

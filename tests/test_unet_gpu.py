@@ -15,7 +15,9 @@ from oracle import cases, nets, synth
 
 pytestmark = pytest.mark.gpu
 S = cases.SEED
-HIP_CASES = ["unet3d", "unet_ldm", "unet_c1"]
+# the last four are the BASELINE configs on their exact kwargs (C2/C4 net at 32^3 x 2 and at 24x40x48; C3b and C5 latent nets)
+# `unet2d_updown`: resblock_updown=True (avg-pool / nearest resnet resamplers)
+HIP_CASES = ["unet3d", "unet_ldm", "unet_c1", "unet_c4", "unet_c4_np2", "unet_c3b", "unet_c5", "unet2d_updown"]
 
 
 def rel_l2(a, b):
@@ -29,7 +31,7 @@ def build(name):
     sd = synth.state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, S)
     ref.load_state_dict(sd)
     net = DiffusionModelUNet(**c["kwargs"])
-    assert list(net.state_dict().keys()).sort() == list(sd.keys()).sort()
+    assert sorted(net.state_dict()) == sorted(sd)
     net.load_state_dict(sd)  # strict
     return c, ref, net.cuda()
 
@@ -160,3 +162,37 @@ def test_class_embedding_matches_oracle():
     assert float(gw[[0, 1, 2, 4]].abs().max()) == 0.0  # untouched rows
     with pytest.raises(ValueError):
         net(xd, t.cuda())
+
+
+def test_controlnet_residuals_match_oracle():
+    """down_block_additional_residuals / mid_block_additional_residual (UNet:1995-2010): one tensor added to every skip and one to
+    the middle block's output; prediction, input gradient and parameter gradients against the CPU restatement."""
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    c = cases.UNET_CASES["unet3d"]
+    ref = nets.DiffusionModelUNet(**c["kwargs"])
+    sd = synth.state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, S)
+    ref.load_state_dict(sd)
+    net = DiffusionModelUNet(**c["kwargs"])
+    net.load_state_dict(sd)
+    net = net.cuda()
+    x, t = synth.tensor(S, "x", c["shape"]), torch.tensor(c["timesteps"])
+    # skip shapes of this net at 16^3: conv_in + (resnet, downsampler) x 2 levels + the last level's resnet
+    n = c["shape"][0]
+    skip_shapes = [(n, 32, 16, 16, 16), (n, 32, 16, 16, 16), (n, 32, 8, 8, 8), (n, 64, 8, 8, 8), (n, 64, 4, 4, 4), (n, 64, 4, 4, 4)]
+    down = [synth.tensor(S, f"ctrl{i}", s, 0.5) for i, s in enumerate(skip_shapes)]
+    mid = synth.tensor(S, "ctrl_mid", (n, 64, 4, 4, 4), 0.5)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr, t, down_block_additional_residuals=down, mid_block_additional_residual=mid)
+    gy = synth.tensor(S, "gy", tuple(yr.shape))
+    yr.backward(gy)
+    xd = x.cuda().requires_grad_(True)
+    y = net(xd, t.cuda(), down_block_additional_residuals=[d.cuda() for d in down], mid_block_additional_residual=mid.cuda())
+    y.backward(gy.cuda())
+    rg = {k: p.grad for k, p in ref.named_parameters() if p.grad is not None}
+    hg = {k: p.grad.cpu() for k, p in net.named_parameters() if p.grad is not None}
+    flat = lambda d: torch.cat([d[k].flatten() for k in sorted(rg)])
+    e_y, e_dx, e_g = rel_l2(y.detach().cpu(), yr.detach()), rel_l2(xd.grad.cpu(), xr.grad), rel_l2(flat(hg), flat(rg))
+    y0 = net(x.cuda(), t.cuda())
+    print(f"\n[ControlNet residuals] prediction {e_y:.3e}, dx {e_dx:.3e}, grads(global) {e_g:.3e}")
+    assert e_y <= 3e-2 and e_dx <= 3e-2 and e_g <= 4e-2
+    assert rel_l2(y0.detach().cpu(), yr.detach()) > 0.1  # the residuals matter: without them the prediction is far off
