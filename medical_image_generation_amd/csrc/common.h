@@ -82,3 +82,22 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 static inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Zero-fill as a KERNEL, never hipMemset[2D]Async: the train step is captured into hipGraphs, and on ROCm 7.2 a memset node of a
+// graph that has been replayed stops zeroing its target once ANOTHER graph is captured in the process (measured: the bias-gradient
+// slab of the captured step kept stale bytes -> inf gradient norm -> every later optimizer step clipped to nothing; tests/
+// test_trainer_gpu.py::test_graph_survives_other_shape_forward).  A kernel node has no such state.
+static __global__ void k_zero_f32_2d(float* __restrict__ x, int64_t ld, int rows, int cols) {
+  const int64_t total = (int64_t)rows * cols;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / cols;
+    x[r * ld + (i - r * cols)] = 0.f;
+  }
+}
+static inline hipError_t mi_zero_fill_f32(float* x, int64_t ld, int rows, int cols, hipStream_t st) {
+  const int64_t total = (int64_t)rows * cols;
+  int grid = (int)((total + 255) / 256);
+  grid = grid < 1 ? 1 : (grid > 2048 ? 2048 : grid);
+  hipLaunchKernelGGL(k_zero_f32_2d, dim3(grid), dim3(256), 0, st, x, ld, rows, cols);
+  return hipGetLastError();
+}

@@ -1295,6 +1295,8 @@ Geom make_geom(int VB, int Do, int Ho, int Wo, const int halo[3], int N, int vox
   g.lds_bytes = g.HD * g.slice;
   g.tilesD = (Do + g.TD - 1) / g.TD; g.tilesH = (Ho + g.TH - 1) / g.TH; g.tilesW = (Wo + g.TW - 1) / g.TW;
   (void)N;
+  static const int hb_env = env_int("MI_TILE_HB", 2);  // rows of tiles per h-block of the tile walk (conv_common.h: tile_origin)
+  g.hb = (hb_env > 1 && g.tilesD > 1 && g.tilesH % hb_env == 0) ? hb_env : 1;
   return g;
 }
 

@@ -605,6 +605,8 @@ __global__ void __launch_bounds__(512, 2) k_conv27(ConvArgs a) {
     if (NCB == 1 && FLIP == 0 && a.stats && wave >= 4) stats_zero<NCB>(a, y, wave - 4, lane);
     return;
   }
+  if (a.dbg & 2) { if (wave < 4) __builtin_amdgcn_s_setprio(3); }   // experiment knobs (MI_C27_DBG): static wave priority
+  if (a.dbg & 4) { if (wave >= 4) __builtin_amdgcn_s_setprio(3); }
   if (wave < 4) compute_role<NCB, FLIP>(a, lds, y, wave, lane, tile0, tile_step, tile_last);
   else helper_role<NCB, NCB == 1 && FLIP == 0>(a, lds, y, wave - 4, lane, tile0, tile_step, tile_last);
 }

@@ -15,6 +15,7 @@ struct Geom {           // tile + LDS geometry (host-computed, passed by value)
   int vox, row, slice;  // byte pitches (voxel: 80 for the b128 fragment reads of fwd/dgrad, 64 for wgrad's transposed reads)
   int lds_bytes;
   int tilesD, tilesH, tilesW;
+  int hb;               // tile walk: rows of tiles per h-block (tile_origin); 1 = plain (w, h, d) raster
 };
 
 struct ConvArgs {
@@ -54,11 +55,26 @@ static __device__ __forceinline__ int first_tile(int ntiles, int& last, int& ste
   return x * tpx + slot;
 }
 
+// Tile index -> tile origin.  Within an image the walk is blocked: w fastest, then the g.hb rows of an h-block, then ALL depths, then
+// the next h-block.  The 32 workgroups of an XCD work on 32 consecutive tiles (first_tile), so with 16 tiles per row and hb = 2 one
+// "depth step" of an XCD is 32 tiles = 2.3 MB of halo reads + stores: the d-halo slices of depth td (a third of every halo image)
+// were read one step earlier and are still in that XCD's 4 MiB L2.  The plain (w, h, d) raster returns to a tile's d-neighbour a
+// whole depth layer (256 tiles, 18 MB at 128^3) later: those reads came from beyond L2.  Images stay outermost (the GroupNorm-sum /
+// bias-gradient epilogues rely on the image index never decreasing along a workgroup's walk).
 static __device__ __forceinline__ void tile_origin(const Geom& g, int tile, int& n, int& d0, int& h0, int& w0) {
   int tw = tile % g.tilesW; tile /= g.tilesW;
-  int th = tile % g.tilesH; tile /= g.tilesH;
-  int td = tile % g.tilesD;
-  n = tile / g.tilesD;
+  int th, td;
+  if (g.hb > 1) {
+    const int hr = tile % g.hb; tile /= g.hb;
+    td = tile % g.tilesD; tile /= g.tilesD;
+    const int nhb = g.tilesH / g.hb;
+    th = (tile % nhb) * g.hb + hr;
+    n = tile / nhb;
+  } else {
+    th = tile % g.tilesH; tile /= g.tilesH;
+    td = tile % g.tilesD;
+    n = tile / g.tilesD;
+  }
   d0 = td * g.TD; h0 = th * g.TH; w0 = tw * g.TW;
 }
 

@@ -563,7 +563,7 @@ int mi_mse_fwd_bwd(const void* pred, const float* target, void* dpred, float* lo
                    hipStream_t st) {
   int64_t total = (int64_t)N * V;
   if (total <= 0) return MI_ERR_BAD_ARG;
-  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+  hipError_t e = mi_zero_fill_f32(loss, 1, 1, 1, st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(k_mse, dim3(grid_for(total, 1024)), dim3(kThreads), 0, st, (const bf16*)pred, target, (bf16*)dpred, loss, C, V, total,
                      1.0f / (float)(total * C), grad_scale);
@@ -574,7 +574,7 @@ int mi_l1_fwd_bwd(const void* pred, const float* target, void* dpred, float* los
   int64_t total = (int64_t)N * V;
   if (total <= 0) return MI_ERR_BAD_ARG;
   if (!accumulate) {
-    hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+    hipError_t e = mi_zero_fill_f32(loss, 1, 1, 1, st);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(k_l1, dim3(grid_for(total, 1024)), dim3(kThreads), 0, st, (const bf16*)pred, target, (bf16*)dpred, loss, C, V, total,
@@ -631,7 +631,7 @@ int mi_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, hipSt
 int mi_colsum_bf16(const void* x, float* out, int out_stride, int N, int64_t V, int C, int accumulate, hipStream_t st) {
   if (C <= 0 || C > 8192 || N <= 0 || V <= 0 || out_stride < C) return MI_ERR_BAD_ARG;
   if (!accumulate) {
-    hipError_t e = hipMemset2DAsync(out, sizeof(float) * (size_t)out_stride, 0, sizeof(float) * (size_t)C, (size_t)N, st);
+    hipError_t e = mi_zero_fill_f32(out, out_stride, N, C, st);
     if (e != hipSuccess) return (int)e;
   }
   if (C & 7) {
@@ -673,7 +673,7 @@ int mi_add_f32_2d(const float* x, int ldx, float* y, int ldy, int rows, int cols
 }
 int mi_zero_f32_2d(float* x, int ld, int rows, int cols, hipStream_t st) {
   if (rows <= 0 || cols <= 0 || ld < cols) return MI_ERR_BAD_ARG;
-  hipError_t e = hipMemset2DAsync(x, sizeof(float) * (size_t)ld, 0, sizeof(float) * (size_t)cols, (size_t)rows, st);
+  hipError_t e = mi_zero_fill_f32(x, ld, rows, cols, st);
   return (int)e;
 }
 int mi_sum_rows_f32(const float* in, int ld, int rows, int cols, float* out, int accumulate, hipStream_t st) {

@@ -85,7 +85,7 @@ extern "C" {
 int mi_sumsq_f32(const float* x, int64_t n, float* out, int accumulate, hipStream_t st) {
   if (n <= 0 || ((uintptr_t)x & 15)) return MI_ERR_BAD_ARG;
   if (!accumulate) {
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+    hipError_t e = mi_zero_fill_f32(out, 1, 1, 1, st);
     if (e != hipSuccess) return (int)e;
   }
   int64_t n4 = n / 4;

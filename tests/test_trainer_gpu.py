@@ -218,12 +218,17 @@ def test_backward_cut_is_sound_and_split_graphs_agree():
         trn._force_split = split
         trn.capture(x0, noise, t)
         assert (trn._g_fb2 is not None) == split
-        losses = [float(trn.step_graph()) for _ in range(2)]
-        out.append((losses, trn.arena.data[:trn.arena.n_trainable].clone()))
-    (l_a, p_a), (l_b, p_b) = out
-    e = float((p_a - p_b).norm() / p_a.norm())
-    print(f"\n[cut] n_late {a.n_late} of {a.n_trainable}; one-graph vs two-graph: losses {l_a} / {l_b}, parameter rel-L2 {e:.2e}")
-    assert all(abs(u - v) <= 1e-5 * abs(u) for u, v in zip(l_a, l_b)) and e <= 1e-6
+        l0 = float(trn.step_graph())
+        g0 = trn.arena.grad[:trn.arena.n_trainable].clone()  # gradients of the first replay: before Adam has amplified anything
+        out.append(([l0, float(trn.step_graph())], g0, trn.arena.data[:trn.arena.n_trainable].clone()))
+    (l_a, g_a, p_a), (l_b, g_b, p_b) = out
+    eg, e = float((g_a - g_b).norm() / g_a.norm()), float((p_a - p_b).norm() / p_a.norm())
+    print(f"\n[cut] n_late {a.n_late} of {a.n_trainable}; one-graph vs two-graph: losses {l_a} / {l_b}, gradient rel-L2 {eg:.2e}, "
+          f"parameters after 2 steps {e:.2e}")
+    # gradients: fp32-atomic summation-order noise only.  Parameters / the second loss: Adam turns that noise into +-lr steps on the
+    # tensors whose exact gradient is zero (to_k.bias, ...), so they agree to a few 1e-4, not to 1e-8
+    assert abs(l_a[0] - l_b[0]) <= 2e-6 * abs(l_a[0]) and eg <= 1e-6
+    assert abs(l_a[1] - l_b[1]) <= 1e-3 * abs(l_a[1]) and e <= 1e-3
 
 
 def test_graph_survives_other_shape_forward():
@@ -255,7 +260,9 @@ def test_graph_survives_other_shape_forward():
     pa, pb = tra.arena.data[:tra.arena.n_trainable], trb.arena.data[:trb.arena.n_trainable]
     e = float((pa - pb).norm() / pb.norm())
     print(f"\n[graph lifetime] losses graph {la} eager {lb}; parameter rel-L2 {e:.2e}")
-    assert all(abs(u - v) <= 1e-4 * abs(v) for u, v in zip(la, lb)) and e <= 1e-5
+    # (the broken replay froze the parameters: losses off by 25 %, parameters by 2e-2; healthy runs differ by Adam's amplification
+    # of fp32-atomic noise on zero-gradient tensors: ~1e-4 in the loss, ~1e-3 in the parameters after three steps at lr 1e-3)
+    assert all(abs(u - v) <= 2e-3 * abs(v) for u, v in zip(la, lb)) and e <= 5e-3
     with pytest.raises(ValueError):
         tra.step(x0.double(), noise[0], t)           # wrong dtype is refused, not misread
     with pytest.raises(ValueError):
