@@ -430,6 +430,7 @@ struct WgradArgs {
   const int* pair_off;  // [npairs] float offset of the pair's slab inside one split's partial
   int64_t split_stride; // floats per split
   int ntiles, nsplit, npairs;
+  int contig;           // k_conv_wgrad2: every XCD class owns a contiguous eighth of the tiles (needs ntiles % 8 == nsplit % 8 == 0)
   int dbg;              // ablation knob (MI_WGRAD_DBG): 1 = stage only the first tile, 2 = skip the MFMA loop
   float* colsum;        // optional: colsum[n * colsum_stride + co] += sum over voxels of dy (bias / time-embedding gradient)
   int colsum_stride;
@@ -888,6 +889,17 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     split = blockIdx.x % w.nsplit;
   }
   if (split >= w.nsplit || pair >= w.npairs || split >= w.ntiles) return;  // whole workgroup, before any barrier
+  // Tile walk.  Workgroups that share blockIdx.x % 8 are observed to share an XCD (speed only).  Interleaved (split, split + nsplit,
+  // ...) the 8 XCDs work on tiles t, t + 1, ..., t + 7: neighbours along W sit on different L2s and every XCD fetches its own copy of
+  // the shared halo columns.  Contiguous: XCD class x owns tiles [x T/8, (x + 1) T/8) and its workgroups stride through them, so
+  // the tiles in flight on one L2 are neighbours in W, H and (with the blocked order of tile_origin) D.
+  int t0 = split, tstep = w.nsplit, tend = w.ntiles;
+  if (w.contig && w.nsplit >= 8) {
+    const int tpx = w.ntiles >> 3;
+    t0 = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / w.npairs;
+    tstep = w.nsplit >> 3;
+    tend = ((blockIdx.x & 7) + 1) * tpx;
+  }
   const int y = pair / a.nchunks;
   const int* hdr = a.hdr + (int64_t)pair * 4;
   const int tap_begin = hdr[0], ntaps = hdr[1], src_c0 = hdr[2];
@@ -907,8 +919,8 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     const int NB = w.nbuf;
     auto request = [&](int t, int slot) {
       int n, d0, h0, w0;
-      const bool valid = t < w.ntiles;
-      tile_origin(g, valid ? t : split, n, d0, h0, w0);
+      const bool valid = t < tend;
+      tile_origin(g, valid ? t : t0, n, d0, h0, w0);
       dma_issue_x<MAXPX>(dx, a, lds + slot * XB, first, 4, px, lane, n, d0, h0, w0, src_c0, valid);
       dma_issue_y<MAXPY>(dyp, w, lds + NB * XB + slot * YB, first, 4, py, lane, y, n, d0, h0, w0, valid);
     };
@@ -916,18 +928,18 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
       if (NB == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    int tile = split, slot = 0;
-    for (int k = 0; k < NB - 1; ++k) request(tile + k * w.nsplit, k);
+    int tile = t0, slot = 0;
+    for (int k = 0; k < NB - 1; ++k) request(tile + k * tstep, k);
     if (NB == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // prologue: tile 0 has landed
     while (true) {
-      const int next = tile + w.nsplit;
+      const int next = tile + tstep;
       const int free_slot = slot == 0 ? NB - 1 : slot - 1;  // released by the barrier that ended the previous iteration
-      request(tile + (NB - 1) * w.nsplit, free_slot);
+      request(tile + (NB - 1) * tstep, free_slot);
       wait_next();
       __builtin_amdgcn_s_barrier();
-      if (next >= w.ntiles) break;
+      if (next >= tend) break;
       tile = next;
       slot = slot + 1 == NB ? 0 : slot + 1;
     }
@@ -954,7 +966,7 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     nt += ti < ntaps ? 1 : 0;
   }
   const int dyrow = g.TW * g.vox, dyslice = g.TH * dyrow;
-  int tile = split, n, d0, h0, w0, buf = 0;
+  int tile = t0, n, d0, h0, w0, buf = 0;
   const int NB = w.nbuf;
   tile_origin(g, tile, n, d0, h0, w0);
   const bool do_colsum = w.colsum != nullptr && (pair % a.nchunks) == 0;
@@ -1018,8 +1030,8 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
       }
     }
     __builtin_amdgcn_s_barrier();  // this tile's buffers are free; the next tile's images have landed
-    const int next = tile + w.nsplit;
-    if (next >= w.ntiles) break;
+    const int next = tile + tstep;
+    if (next >= tend) break;
     tile = next;
     buf = buf + 1 == NB ? 0 : buf + 1;
     tile_origin(g, tile, n, d0, h0, w0);
@@ -1842,6 +1854,8 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   w.part = P->d_part; w.pair_off = P->d_pair_off; w.split_stride = P->wg_split_stride;
   w.ntiles = P->N * a.g.tilesD * a.g.tilesH * a.g.tilesW;
   w.nsplit = P->wg_nsplit;
+  static const int contig_env = env_int("MI_WGRAD_CONTIG", 1);
+  w.contig = contig_env && (w.ntiles % 8 == 0) && (w.nsplit % 8 == 0) && w.nsplit <= w.ntiles;
   static const int dbg = env_int("MI_WGRAD_DBG", 0);
   w.dbg = dbg;
   w.colsum = dy_colsum; w.colsum_stride = dy_colsum_stride;

@@ -10,6 +10,7 @@ FETCH_SIZE / WRITE_SIZE are reported in KB; FETCH_SIZE counts 128-byte requests 
 doubled.  The per-dispatch CSV rows of the two kernels are copied next to the summary so the numbers can be re-derived."""
 import collections
 import csv
+import re
 import glob
 import json
 import os
@@ -34,8 +35,10 @@ def main():
             for f in glob.glob(os.path.join(src, f"pmc_{kind}_{counter}", "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     if r["Counter_Name"] == counter and (sub in r["Kernel_Name"] or "k_wgrad_reduce" in r["Kernel_Name"]):
-                        acc[r["Kernel_Name"].split("(")[0][:60]].append(float(r["Counter_Value"]))
-                        rows_out.append({"pass": f"{kind}/{counter}", "kernel": r["Kernel_Name"].split("(")[0][:60],
+                        m = re.search(r"k_\w+(<[^>]*>)?", r["Kernel_Name"])
+                        kname = m.group(0) if m else r["Kernel_Name"][:60]
+                        acc[kname].append(float(r["Counter_Value"]))
+                        rows_out.append({"pass": f"{kind}/{counter}", "kernel": kname,
                                          "dispatch": r.get("Dispatch_Id", ""), "value_KB": r["Counter_Value"]})
             # launches 2.. of each kernel (the first also pays cold caches / the plan's first touch)
             vals[counter] = {k: sum(v[1:]) / max(len(v) - 1, 1) for k, v in acc.items()}
