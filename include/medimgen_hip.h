@@ -43,7 +43,7 @@ int mi_copy_channels(const void* src, int Cs, int c0s, void* dst, int Cd, int c0
 int mi_upsample_nearest_fwd(const void* x, void* y, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t stream);
 int mi_upsample_nearest_bwd(const void* dy, void* dx, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t stream);
 /* space<->depth rearrangement used by strided convolutions; (D,H,W,C) always describe the SPACE-side tensor */
-int mi_space_to_depth(const void* in, void* out, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t stream);
+int mi_space_to_depth(const void* in, int in_cstride, void* out, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t stream);
 int mi_depth_to_space(const void* in, void* out, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t stream);
 
 /* ---- aten::native_group_norm (+backward) fused with aten::silu: nn.GroupNorm + nn.SiLU, UNet:628-629,648,377,1932-1933;
@@ -158,6 +158,13 @@ int mi_logvar_to_sigma_bwd(const void* dsigma, const void* logvar, const void* s
  * the backward is a gather over the (possibly overlapping) windows containing each input voxel ----------------------------- */
 int mi_avgpool_fwd(const void* x, void* y, int N, int D, int H, int W, int C, const int kernel[3], const int stride[3], hipStream_t stream);
 int mi_avgpool_bwd(const void* dy, void* dx, int N, int D, int H, int W, int C, const int kernel[3], const int stride[3], hipStream_t stream);
+
+/* ---- data path: crop_and_pad_nd (medimgen/data_processing.py:148-225) + the clamp of MedicalDataset.__getitem__
+ * (:595) on a volume RESIDENT in HBM.  src: [C][D][H][W] fp32 (or fp16 when src_is_f16); out: [C][oD][oH][oW] fp32 with lower corner
+ * lo[3] (negative / past-the-end corners are padded with pad_value); flip_mask bit 0/1/2 mirrors the patch along D/H/W
+ * (MirrorTransform of the soft augmentation, :399-416); out = clamp01 ? clamp(v * scale, 0, 1) : v * scale -------------------- */
+int mi_crop_pad(const void* src, int src_is_f16, int C, int D, int H, int W, const int lo[3], float* out, int oD, int oH, int oW,
+                float pad_value, int flip_mask, float scale, int clamp01, hipStream_t stream);
 
 /* ---- train-step glue: scheduler.add_noise (T-LDM:160), F.mse_loss (+backward) (T-LDM:169, T-DDPM:192) ------------------- */
 int mi_qsample(const float* x0, const float* noise, const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod,

@@ -27,7 +27,7 @@ _SIGS = {
     "mi_copy_channels": [_p, _i, _i, _p, _i, _i, _i, _l, _p],
     "mi_upsample_nearest_fwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "mi_upsample_nearest_bwd": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
-    "mi_space_to_depth": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "mi_space_to_depth": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "mi_depth_to_space": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "mi_gn_workspace_bytes": [_i, _l, _i],
     "mi_gn_stats": [_p, _i, _i, _l, _i, _i, _f, _p, _p, _p, _p, _p, _l, _p],
@@ -67,6 +67,7 @@ _SIGS = {
     "mi_embedding_bwd": [_p, _p, _p, _i, _i, _p],
     "mi_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
+    "mi_crop_pad": [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p],
     "mi_qsample": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
     "mi_ddpm_step": [_p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
     "mi_mse_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _f, _p],

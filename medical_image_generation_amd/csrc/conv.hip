@@ -1729,8 +1729,7 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
   const bf16* src = (const bf16*)x;
   int src_cs = x_cs;
   if (P->strided) {
-    if (x_cs != P->Cin) return MI_ERR_UNSUPPORTED;
-    int e = mi_space_to_depth(x, P->d_xs, P->N, P->Di, P->Hi, P->Wi, P->Cin, P->f[0], P->f[1], P->f[2], st);
+    int e = mi_space_to_depth(x, x_cs, P->d_xs, P->N, P->Di, P->Hi, P->Wi, P->Cin, P->f[0], P->f[1], P->f[2], st);
     if (e) return e;
     src = P->d_xs;
     src_cs = P->Q * P->Cin;
@@ -1832,8 +1831,7 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   const bf16* src = (const bf16*)x;
   int src_cs = x_cs;
   if (P->strided) {
-    if (x_cs != P->Cin) return MI_ERR_UNSUPPORTED;
-    int e = mi_space_to_depth(x, P->d_xs, P->N, P->Di, P->Hi, P->Wi, P->Cin, P->f[0], P->f[1], P->f[2], st);
+    int e = mi_space_to_depth(x, x_cs, P->d_xs, P->N, P->Di, P->Hi, P->Wi, P->Cin, P->f[0], P->f[1], P->f[2], st);
     if (e) return e;
     src = P->d_xs;
     src_cs = P->Q * P->Cin;

@@ -169,8 +169,9 @@ __global__ void k_avgpool_bwd(const bf16* __restrict__ dy, bf16* __restrict__ dx
 // ---------------------------------------------------------------- space <-> depth (per-axis factor 1 or 2)
 // s2d: out[n, d', h', w', q*C + c] = in[n, d'*fd + qd, h'*fh + qh, w'*fw + qw, c], q = (qd*fh + qh)*fw + qw
 // (positions beyond the input extent read as zero: odd sizes).  d2s is the inverse scatter.
+// scs8: voxel pitch of the SPACE-side tensor in 16-byte units (>= C8: it may be a channel slice of a wider buffer)
 __global__ void k_space_depth(const bf16* __restrict__ in, bf16* __restrict__ out, int D, int H, int W, int C8, int fd, int fh,
-                              int fw, int Dp, int Hp, int Wp, int to_depth, int64_t total) {
+                              int fw, int Dp, int Hp, int Wp, int to_depth, int64_t total, int scs8) {
   int Q = fd * fh * fw;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     // i enumerates the DEPTH-side tensor: [n, Dp, Hp, Wp, Q, C8]
@@ -184,13 +185,40 @@ __global__ void k_space_depth(const bf16* __restrict__ in, bf16* __restrict__ ou
     int qw = q % fw, qh = (q / fw) % fh, qd = q / (fw * fh);
     int sd = d * fd + qd, sh = h * fh + qh, sw = w * fw + qw;
     bool inside = sd < D && sh < H && sw < W;
-    int64_t sp = (((n * D + sd) * H + sh) * W + sw) * C8 + c;
+    int64_t sp = (((n * D + sd) * H + sh) * W + sw) * scs8 + c;
     if (to_depth) {
       u32x4 z = {0u, 0u, 0u, 0u};
       ((u32x4*)out)[i] = inside ? ((const u32x4*)in)[sp] : z;
     } else if (inside) {
       ((u32x4*)out)[sp] = ((const u32x4*)in)[i];
     }
+  }
+}
+
+// ---------------------------------------------------------------- patch cutter of the data path (medimgen/data_processing.py)
+// crop_and_pad_nd (DATA:148-225) fused with the cheap tail of MedicalDataset.__getitem__ (DATA:586-595): the volume stays resident
+// in HBM (fp32 or fp16, [C][D][H][W]); one launch cuts one [C][oD][oH][oW] fp32 patch whose lower corner is `lo` (may be negative /
+// run past the volume: pad_value there), optionally mirrors it along the axes of flip_mask (bit 0 = D, 1 = H, 2 = W), multiplies
+// by `scale` and clamps to [0, 1].  HBM-bound: one read and one write per output element, the W axis on the lanes.
+template <typename T>
+__global__ void k_crop_pad(const T* __restrict__ src, float* __restrict__ out, int C, int D, int H, int W, int l0, int l1, int l2, int oD, int oH,
+                           int oW, float pad, int flip, float scale, int clamp01, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int x = (int)(i % oW);
+    int64_t t = i / oW;
+    int y = (int)(t % oH); t /= oH;
+    int z = (int)(t % oD);
+    const int64_t c = t / oD;
+    if (flip & 1) z = oD - 1 - z;
+    if (flip & 2) y = oH - 1 - y;
+    if (flip & 4) x = oW - 1 - x;
+    const int sz = l0 + z, sy = l1 + y, sx = l2 + x;
+    float v = pad;
+    if ((unsigned)sz < (unsigned)D && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W)
+      v = (float)src[((c * D + sz) * H + sy) * (int64_t)W + sx];
+    v *= scale;
+    if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    out[i] = v;
   }
 }
 
@@ -498,11 +526,12 @@ int mi_upsample_nearest_bwd(const void* dy, void* dx, int N, int D, int H, int W
   MI_CHECK_LAUNCH();
   return 0;
 }
-int mi_space_to_depth(const void* in, void* out, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t st) {
+int mi_space_to_depth(const void* in, int in_cs, void* out, int N, int D, int H, int W, int C, int fd, int fh, int fw, hipStream_t st) {
+  if (in_cs < C || (in_cs & 7)) return MI_ERR_BAD_ARG;
   if (C & 7) return MI_ERR_BAD_ARG;
   int Dp = (D + fd - 1) / fd, Hp = (H + fh - 1) / fh, Wp = (W + fw - 1) / fw;
   int64_t total = (int64_t)N * Dp * Hp * Wp * fd * fh * fw * (C / 8);
-  hipLaunchKernelGGL(k_space_depth, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)in, (bf16*)out, D, H, W, C / 8, fd, fh, fw, Dp, Hp, Wp, 1, total);
+  hipLaunchKernelGGL(k_space_depth, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)in, (bf16*)out, D, H, W, C / 8, fd, fh, fw, Dp, Hp, Wp, 1, total, in_cs / 8);
   MI_CHECK_LAUNCH();
   return 0;
 }
@@ -511,7 +540,7 @@ int mi_depth_to_space(const void* in, void* out, int N, int D, int H, int W, int
   if (C & 7) return MI_ERR_BAD_ARG;
   int Dp = (D + fd - 1) / fd, Hp = (H + fh - 1) / fh, Wp = (W + fw - 1) / fw;
   int64_t total = (int64_t)N * Dp * Hp * Wp * fd * fh * fw * (C / 8);
-  hipLaunchKernelGGL(k_space_depth, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)in, (bf16*)out, D, H, W, C / 8, fd, fh, fw, Dp, Hp, Wp, 0, total);
+  hipLaunchKernelGGL(k_space_depth, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)in, (bf16*)out, D, H, W, C / 8, fd, fh, fw, Dp, Hp, Wp, 0, total, C / 8);
   MI_CHECK_LAUNCH();
   return 0;
 }
@@ -538,6 +567,19 @@ int mi_avgpool_bwd(const void* dy, void* dx, int N, int D, int H, int W, int C, 
   int64_t total = (int64_t)N * D * H * W * (C / 8);
   hipLaunchKernelGGL(k_avgpool_bwd, dim3(grid_for(total)), dim3(kThreads), 0, st, (const bf16*)dy, (bf16*)dx, D, H, W, C / 8, kernel[0], kernel[1],
                      kernel[2], stride[0], stride[1], stride[2], o[0], o[1], o[2], total);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+int mi_crop_pad(const void* src, int src_is_f16, int C, int D, int H, int W, const int lo[3], float* out, int oD, int oH, int oW,
+                float pad_value, int flip_mask, float scale, int clamp01, hipStream_t st) {
+  if (!src || !out || !lo || C <= 0 || D <= 0 || H <= 0 || W <= 0 || oD <= 0 || oH <= 0 || oW <= 0) return MI_ERR_BAD_ARG;
+  const int64_t total = (int64_t)C * oD * oH * oW;
+  if (src_is_f16)
+    hipLaunchKernelGGL(k_crop_pad<_Float16>, dim3(grid_for(total)), dim3(kThreads), 0, st, (const _Float16*)src, out, C, D, H, W, lo[0], lo[1], lo[2],
+                       oD, oH, oW, pad_value, flip_mask, scale, clamp01, total);
+  else
+    hipLaunchKernelGGL(k_crop_pad<float>, dim3(grid_for(total)), dim3(kThreads), 0, st, (const float*)src, out, C, D, H, W, lo[0], lo[1], lo[2], oD,
+                       oH, oW, pad_value, flip_mask, scale, clamp01, total);
   MI_CHECK_LAUNCH();
   return 0;
 }

@@ -400,30 +400,37 @@ def concat_buffer(a_shape, ca, cb, device):
 
 
 def concat(ctx: Ctx, a, b, buf=None):
-    """torch.cat([a, b], channel axis) (UNet:1263, 1377, 1504).  buf: buffer from concat_buffer whose first channels ARE `a`
-    (then only b is copied); in backward d(a) is then a channel-slice VIEW of d(cat), not a copy."""
-    in_place = buf is not None and a.data_ptr() == buf.data_ptr()
-    if in_place:
-        n, v, cb_ = a.shape[0], a.shape[1] * a.shape[2] * a.shape[3], b.shape[-1]
-        call("mi_copy_channels", ptr(b), ops._cs(b), 0, ptr(buf), buf.shape[-1], a.shape[-1], cb_, n * v)
+    """torch.cat([a, b], channel axis) (UNet:1263, 1377, 1504).  buf: the concatenation's buffer when one or both halves already
+    live in it -- `a` written there by its producing conv (concat_buffer), `b` (the skip) written there when it was produced
+    (unet._run: skip slots).  Only the halves that are elsewhere are copied; in backward the gradient of an in-place half is a
+    channel-slice VIEW of d(cat), not a copy."""
+    ca, cb = a.shape[-1], b.shape[-1]
+    a_in = buf is not None and a.data_ptr() == buf.data_ptr() and ops._cs(a) == ca + cb
+    b_in = buf is not None and b.data_ptr() == buf.data_ptr() + 2 * ca and ops._cs(b) == ca + cb
+    if a_in or b_in:
+        n, v = a.shape[0], a.shape[1] * a.shape[2] * a.shape[3]
+        if not a_in:
+            call("mi_copy_channels", ptr(a), ops._cs(a), 0, ptr(buf), ca + cb, 0, ca, n * v)
+        if not b_in:
+            call("mi_copy_channels", ptr(b), ops._cs(b), 0, ptr(buf), ca + cb, ca, cb, n * v)
         y = buf
     else:
         y = ops.concat_channels(a, b)
     ctx.cat_parts[id(y)] = (a, b, weakref.ref(y))
     if ctx.tape is not None:
         tape = ctx.tape
-        ca, cb = a.shape[-1], b.shape[-1]
 
         def bwd():
             dy = tape.take(y)
-            if dy is not None:
-                if in_place and id(a) not in tape.grads:  # sole consumer of `a`: hand the slice over as a strided view
-                    tape.grads[id(a)] = dy[..., :ca]
-                    tape.keep.append(a)
+            if dy is None:
+                return
+            for t, lo, n_c, in_place in ((a, 0, ca, a_in), (b, ca, cb, b_in)):
+                if in_place and id(t) not in tape.grads:  # first gradient of this half: hand the slice over as a strided view
+                    tape.grads[id(t)] = dy[..., lo:lo + n_c]
+                    tape.keep.append(t)
                     tape.keep.append(dy)
                 else:
-                    tape.put(a, ops.slice_channels(dy, 0, ca))
-                tape.put(b, ops.slice_channels(dy, ca, cb))
+                    tape.put(t, ops.slice_channels(dy, lo, n_c))
 
         tape.record(bwd)
     return y

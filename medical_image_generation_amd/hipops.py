@@ -88,6 +88,7 @@ def dense(t):
 
 
 def upsample_nearest(x, f):
+    x = dense(x)
     n, d, h, w, c = x.shape
     out = torch.empty((n, d * f[0], h * f[1], w * f[2], c), dtype=BF16, device=x.device)
     call("mi_upsample_nearest_fwd", ptr(x), ptr(out), n, d, h, w, c, f[0], f[1], f[2])
@@ -107,8 +108,8 @@ def _pool_out(dims, kernel, stride):
 
 def avg_pool(x, kernel, stride):
     """nn.AvgPool{2,3}d(kernel_size, stride) (no padding, floor mode) on NDHWC bf16."""
+    x = dense(x)  # (a skip living in its concatenation buffer is a channel-slice view)
     n, d, h, w, c = x.shape
-    assert x.is_contiguous()
     od, oh, ow = _pool_out((d, h, w), kernel, stride)
     out = torch.empty((n, od, oh, ow, c), dtype=BF16, device=x.device)
     arr = lambda v: (C.c_int * 3)(*v)

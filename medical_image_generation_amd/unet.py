@@ -22,6 +22,8 @@ from . import hipops as ops
 from ._lib import call, ptr
 
 F32 = torch.float32
+import os as _os  # noqa: E402
+SKIP_SLOTS = _os.environ.get("MI_SKIP_SLOTS", "1") == "1"  # skips written straight into their concatenation buffers (_run); 0: copied
 
 
 class _Tree(nn.Module):
@@ -341,6 +343,14 @@ class DiffusionModelUNet(HipModule):
         late_pre = tuple(f"down_blocks.{i}." for i in range(self._cut_level + 1)) + ("conv_in.", "time_embed.", "class_embedding.")
         late = [n for n, _, _ in spec.order if n.startswith(late_pre) or ".time_emb_proj." in n or n.endswith(".conv1.conv.bias")]
         self._init_plumbing(spec, groups, late)
+        # Channels of the tensor each skip will be concatenated BEHIND (UNet:1263: cat([h, skip])), in the order the skips are produced:
+        # a skip is written straight into the last channels of its concatenation buffer (_run), so the up path copies nothing.
+        rch_, rnrb_ = list(reversed(ch)), list(reversed(nrb))
+        pops = []
+        for i in range(L):
+            for j in range(rnrb_[i] + 1):
+                pops.append((rch_[i - 1] if i > 0 else rch_[0]) if j == 0 else rch_[i])
+        self._skip_ca = list(reversed(pops))
         self._temb_off = {}
         off = 0
         for name, _, cout in self._resnets:
@@ -402,46 +412,76 @@ class DiffusionModelUNet(HipModule):
             c.tape.record(bwd_emb)
 
         k3 = (1,) * (3 - sd) + (3,) * sd
-        h = E.conv(c, x_cl, "conv_in.conv", self._k[0], self._s[0], self._p[0], need_dx=need_dx)
-        skips = [h]
+        # Skip slots.  Every tensor the down path pushes on the skip stack is later the SECOND half of a channel concatenation with a
+        # known first half (self._skip_ca).  Its producer therefore writes it straight into the last channels of that concatenation's
+        # buffer (a channel-slice view: every kernel takes a voxel pitch), and the first half is written there by ITS producer when
+        # the up path gets to it: torch.cat costs nothing in either direction.  Producers that cannot write through a view
+        # (attention; ControlNet sums) fall back to one copy.
+        slots = down_res is None and SKIP_SLOTS
+        skips = []  # (tensor, concat buffer or None)
+
+        def slot(dims, cb):
+            """(buffer, view of its last cb channels) for the next skip to be produced, or (None, None)."""
+            if not slots:
+                return None, None
+            ca = self._skip_ca[len(skips)]
+            buf = torch.empty((x_cl.shape[0],) + tuple(dims) + (ca + cb,), dtype=torch.bfloat16, device=dev)
+            return buf, buf[..., ca:]
+
+        def conv_dims(dims, k, s, p):
+            return tuple((d + 2 * pp - kk) // ss + 1 for d, kk, ss, pp in zip(dims, k, s, p))
+
+        buf, view = slot(conv_dims(x_cl.shape[1:4], self._k[0], self._s[0], self._p[0]), ch[0])
+        h = E.conv(c, x_cl, "conv_in.conv", self._k[0], self._s[0], self._p[0], need_dx=need_dx, out=view)
+        skips.append((h, buf))
         for i in range(L):
             for j in range(self.num_res_blocks[i]):
-                h = self._resnet(c, h, f"down_blocks.{i}.resnets.{j}", temb_all, d_temb_all)
-                if self.attention_levels[i]:
+                att = self.attention_levels[i]
+                buf, view = (None, None) if att else slot(h.shape[1:4], ch[i])
+                h = self._resnet(c, h, f"down_blocks.{i}.resnets.{j}", temb_all, d_temb_all, out=view)
+                if att:
                     h = self._attention(c, h, f"down_blocks.{i}.attentions.{j}", self._heads(ch[i], self.num_head_channels[i]))
-                skips.append(h)
+                skips.append((h, buf))
             if i != L - 1:
                 if self.resblock_updown:
                     h = self._resnet(c, h, f"down_blocks.{i}.downsampler", temb_all, d_temb_all, mode="down", stride=self._s[i + 1],
                                      kernel=self._k[i + 1])
+                    skips.append((h, None))
                 else:
-                    h = E.conv(c, h, f"down_blocks.{i}.downsampler.op.conv", self._k[i + 1], self._s[i + 1], self._p[i + 1])
-                skips.append(h)
+                    buf, view = slot(conv_dims(h.shape[1:4], self._k[i + 1], self._s[i + 1], self._p[i + 1]), ch[i])
+                    h = E.conv(c, h, f"down_blocks.{i}.downsampler.op.conv", self._k[i + 1], self._s[i + 1], self._p[i + 1], out=view)
+                    skips.append((h, buf))
             if i == self._cut_level and grad:
                 c.tape.record(E.CUT)  # backward order: everything recorded after this point has run when the tape gets here
         if down_res is not None:  # ControlNet residuals: one per skip, added before the up path reads them (UNet:1995-2003)
             if len(down_res) != len(skips):
                 raise ValueError(f"down_block_additional_residuals must hold {len(skips)} tensors, got {len(down_res)}")
-            skips = [E.add(c, sk, r, b_needs_grad=False) for sk, r in zip(skips, down_res)]
+            skips = [(E.add(c, sk, r, b_needs_grad=False), None) for (sk, _), r in zip(skips, down_res)]
         h = self._resnet(c, h, "middle_block.resnet_1", temb_all, d_temb_all)
         h = self._attention(c, h, "middle_block.attention", self._heads(ch[-1], self.num_head_channels[-1]))
-        # Whatever feeds a skip concatenation (UNet:1263, 1377, 1504) is written by its producing conv straight into the first
-        # channels of the concat buffer: only the skip half is copied, and in backward d(producer output) is a view of d(cat).
+
+        # Whatever feeds a skip concatenation (UNet:1263, 1377, 1504) is written by its producing conv straight into the FIRST
+        # channels of the concat buffer (the skip's slot buffer when it has one), and in backward its gradient is a view of d(cat).
         def cat_buffer(ca):
-            return E.concat_buffer(skips[-1].shape, ca, skips[-1].shape[-1], dev)
+            sk, sbuf = skips[-1]
+            if sbuf is not None and sbuf.shape[-1] == ca + sk.shape[-1]:
+                return sbuf, sbuf[..., :ca]
+            return E.concat_buffer(sk.shape, ca, sk.shape[-1], dev)
 
         pending, view = cat_buffer(ch[-1])
         h = self._resnet(c, h, "middle_block.resnet_2", temb_all, d_temb_all, out=None if mid_res is not None else view)
         if mid_res is not None:  # UNet:2008-2010
             h = E.add(c, h, mid_res, b_needs_grad=False)
-            pending, view = None, None
         rch, rnrb = list(reversed(ch)), list(reversed(self.num_res_blocks))
         ratt, rnhc = list(reversed(self.attention_levels)), list(reversed(self.num_head_channels))
         rs, rp = list(reversed(self._s)), list(reversed(self._p))
         for i in range(L):
             n_res = rnrb[i] + 1
             for j in range(n_res):
-                h = E.concat(c, h, skips.pop(), buf=pending)
+                sk, sbuf = skips.pop()
+                if pending is None or (sbuf is not None and pending is not sbuf):  # h was not produced into a buffer: use the skip's
+                    pending = sbuf if sbuf is not None and sbuf.shape[-1] == h.shape[-1] + sk.shape[-1] else pending
+                h = E.concat(c, h, sk, buf=pending)
                 pending, view = (None, None)
                 if j < n_res - 1 and not ratt[i]:  # this resnet's output is the next concat's first half
                     pending, view = cat_buffer(rch[i])
