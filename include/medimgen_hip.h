@@ -153,6 +153,18 @@ int mi_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, hipSt
 int mi_logvar_to_sigma_fwd(const void* logvar, void* sigma, int64_t n, hipStream_t stream);
 int mi_logvar_to_sigma_bwd(const void* dsigma, const void* logvar, const void* sigma, void* dlogvar, int64_t n, hipStream_t stream);
 
+/* ---- cross-attention path (SpatialTransformer / BasicTransformerBlock / CrossAttention, UNet:72-342): nn.LayerNorm over token rows
+ * (x, y, dy, dx: bf16 [M][ld]; gamma / beta / dgamma / dbeta fp32 [C]; mean_rstd fp32 [M][2]; C % 8 == 0, C <= 1024; dgamma / dbeta
+ * are accumulated) and the GEGLU gate of the feed-forward, monai MLPBlock(act="GEGLU") (UNet:211): h bf16 [M][2F] -> y[M][F] =
+ * h[:, :F] * gelu(h[:, F:]) with the exact (erf) GELU.  The projections run on mi_gemm_nt_bf16 / mi_linear_wgrad_bf16, the
+ * attention core on the mi_gemm / mi_softmax / mi_transpose family (query and key/value token counts may differ) ------------- */
+int mi_layernorm_fwd(const void* x, int ldx, const float* gamma, const float* beta, void* y, int ldy, float* mean_rstd, int64_t M, int C,
+                     float eps, hipStream_t stream);
+int mi_layernorm_bwd(const void* dy, int lddy, const void* x, int ldx, const float* gamma, const float* mean_rstd, void* dx, int lddx,
+                     float* dgamma, float* dbeta, int64_t M, int C, hipStream_t stream);
+int mi_geglu_fwd(const void* h, void* y, int64_t M, int F, hipStream_t stream);
+int mi_geglu_bwd(const void* h, const void* dy, void* dh, int64_t M, int F, hipStream_t stream);
+
 /* ---- nn.AvgPool{2,3}d(kernel_size, stride), no padding, floor mode: the resampler of ResnetBlock(down=True) under
  * resblock_updown=True (UNet:522, 640-644, 679-687).  NDHWC bf16, C % 8 == 0; (D, H, W) are the INPUT extents for both calls;
  * the backward is a gather over the (possibly overlapping) windows containing each input voxel ----------------------------- */

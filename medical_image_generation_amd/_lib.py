@@ -65,6 +65,10 @@ _SIGS = {
     "mi_logvar_to_sigma_bwd": [_p, _p, _p, _p, _l, _p],
     "mi_embedding_add": [_p, _p, _p, _i, _i, _p],
     "mi_embedding_bwd": [_p, _p, _p, _i, _i, _p],
+    "mi_layernorm_fwd": [_p, _i, _p, _p, _p, _i, _p, _l, _i, _f, _p],
+    "mi_layernorm_bwd": [_p, _i, _p, _i, _p, _p, _p, _i, _p, _p, _l, _i, _p],
+    "mi_geglu_fwd": [_p, _p, _l, _i, _p],
+    "mi_geglu_bwd": [_p, _p, _p, _l, _i, _p],
     "mi_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_crop_pad": [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p],

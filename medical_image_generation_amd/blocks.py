@@ -199,3 +199,41 @@ class ResBlock(_Block):
             return (E.conv(c, h, "conv2.conv", k3, s1, p1, norm=n2, silu=True, res=xs),), {"x_cl": x_cl}
 
         return self._edge(runner, x)
+
+
+class SpatialTransformer(_Block):
+    """Transformer block for image-like data (UNet:237-342): GroupNorm -> 1x1 proj_in -> num_layers x [self-attention,
+    cross-attention on `context`, GEGLU feed-forward] -> 1x1 proj_out (zero-initialised) + input.  The feed-forward is monai's
+    MLPBlock(act="GEGLU") (third-party; restated).  `context`: [B, tokens, cross_attention_dim] or None (attn2 then attends to the
+    block's own tokens, UNet:159); it is treated as a constant (no gradient is returned for it)."""
+
+    def __init__(self, spatial_dims: int, in_channels: int, num_attention_heads: int, num_head_channels: int, num_layers: int = 1,
+                 dropout: float = 0.0, norm_num_groups: int = 32, norm_eps: float = 1e-6, cross_attention_dim: int | None = None,
+                 upcast_attention: bool = False, use_flash_attention: bool = False) -> None:
+        super().__init__()
+        if use_flash_attention:
+            raise ValueError("use_flash_attention is True but xformers is not installed.")
+        if dropout > 0.0:
+            raise NotImplementedError("dropout > 0 is not on the HIP path (the reference's default is 0.0)")
+        if num_attention_heads * num_head_channels != in_channels:
+            raise NotImplementedError("the HIP path covers inner_dim == in_channels (how every block of the U-Net constructs it, UNet:976-990)")
+        self.spatial_dims, self.in_channels = spatial_dims, in_channels
+        self.heads, self.layers, self.groups, self.eps = num_attention_heads, num_layers, norm_num_groups, norm_eps
+        self.cross_attention_dim = cross_attention_dim if cross_attention_dim is not None else in_channels
+        spec = ParamSpec(self, spatial_dims)
+        spec.transformer("", in_channels, self.cross_attention_dim, num_layers)
+        self._init_plumbing(spec, [])
+
+    def forward(self, x: torch.Tensor, context: torch.Tensor | None = None) -> torch.Tensor:
+        self._check(x, self.in_channels, f"expected {self.in_channels} input channels, got {x.shape[1]}")
+        ctx_tokens = None
+        if context is not None:
+            if context.dim() != 3 or context.shape[0] != x.shape[0] or context.shape[2] != self.cross_attention_dim:
+                raise ValueError(f"context must be [batch, tokens, {self.cross_attention_dim}], got {tuple(context.shape)}")
+            ctx_tokens = ops.cast_bf16(context.detach().to(x.device).contiguous().float().reshape(-1, context.shape[2]))
+
+        def runner(c, xin, need_dx):
+            x_cl = ops.to_channels_last(xin.contiguous().float())
+            return (E.spatial_transformer(c, x_cl, "", ctx_tokens, self.groups, self.eps, self.heads, self.layers),), {"x_cl": x_cl}
+
+        return self._edge(runner, x)

@@ -605,3 +605,184 @@ def linear_f32(x_f32, w, b, gw, gb):
         return dx
 
     return y, bwd
+
+
+# --------------------------------------------------------------------------------------------- cross-attention path (UNet:72-342)
+def _reshape(ctx: Ctx, x, shape):
+    """x viewed with another shape (same storage): channels-last activations ARE the [B*S, C] token matrix (UNet:327-330 for free)."""
+    y = x.view(shape)
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            g = tape.take(y)
+            if g is not None:
+                tape.put(x, ops.dense(g).view(x.shape))
+
+        tape.record(bwd)
+    return y
+
+
+def layernorm(ctx: Ctx, x, name, eps=1e-5):
+    """nn.LayerNorm(C) over token rows x [M, C] bf16 (UNet:219-221)."""
+    m, c = x.shape
+    gamma, beta = ctx.p(name + ".weight"), ctx.p(name + ".bias")
+    y = torch.empty_like(x)
+    mr = torch.empty((m, 2), dtype=F32, device=x.device)
+    call("mi_layernorm_fwd", ptr(x), c, ptr(gamma), ptr(beta), ptr(y), c, ptr(mr), m, c, float(eps))
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is None:
+                return
+            dx = torch.empty_like(x)
+            call("mi_layernorm_bwd", ptr(dy), c, ptr(x), c, ptr(gamma), ptr(mr), ptr(dx), c, ptr(ctx.g(name + ".weight")),
+                 ptr(ctx.g(name + ".bias")), m, c)
+            tape.put(x, dx)
+
+        tape.record(bwd)
+    return y
+
+
+def linear(ctx: Ctx, x, name, bias=True, res=None, need_dx=True):
+    """nn.Linear on token rows: y = x W^T (+ b) (+ res).  x [M, K] bf16 dense, W fp32 [N, K] in the arena (bf16 MFMA, fp32 accumulate)."""
+    m, k = x.shape
+    w = ctx.p(name + ".weight")
+    n = w.shape[0]
+    if k % 8 or n % 8:
+        raise ValueError(f"{name}: feature counts must be multiples of 8 on the HIP path (got {k} -> {n})")
+    wb = ops.cast_bf16(w)
+    y = torch.empty((m, n), dtype=BF16, device=x.device)
+    _gemm(x, k, 0, 0, wb, k, 0, 0, y, n, 0, 0, m, n, k, 1, 1, bias=ctx.p(name + ".bias") if bias else None, res=res, ldr=n)
+    ctx.count(2 * m * n * k, dgrad=need_dx)
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is None:
+                return
+            call("mi_linear_wgrad_bf16", ptr(x), k, k, ptr(dy), n, n, m, ptr(ctx.g(name + ".weight")), ptr(ctx.g(name + ".bias")) if bias else None)
+            if res is not None:
+                tape.put(res, dy)
+            if need_dx:
+                wt = _transpose(wb, k, 0, 0, n, k, 1, 1, x.device)[0]  # [K, N]
+                dx = torch.empty((m, k), dtype=BF16, device=x.device)
+                _gemm(dy, n, 0, 0, wt, n, 0, 0, dx, k, 0, 0, m, k, n, 1, 1)
+                tape.put(x, dx)
+
+        tape.record(bwd)
+    return y
+
+
+def geglu(ctx: Ctx, h):
+    """GEGLU of monai's MLPBlock(act="GEGLU") (UNet:211): h [M, 2F] -> h[:, :F] * gelu(h[:, F:])."""
+    m, f2 = h.shape
+    f = f2 // 2
+    y = torch.empty((m, f), dtype=BF16, device=h.device)
+    call("mi_geglu_fwd", ptr(h), ptr(y), m, f)
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is not None:
+                dh = torch.empty_like(h)
+                call("mi_geglu_bwd", ptr(h), ptr(dy), ptr(dh), m, f)
+                tape.put(h, dh)
+
+        tape.record(bwd)
+    return y
+
+
+def mha(ctx: Ctx, q, k, v, b, sq, skv, heads):
+    """CrossAttention._attention (UNet:135-154): softmax(Q K^T / sqrt(d)) V per head; q [B*Sq, C], k / v [B*Skv, C] bf16 dense, the
+    heads are column slices (reshape_heads_to_batch_dim is free in this layout).  Materialised scores (fp32) -- the query and
+    key/value token counts differ for a context -- with every token axis that becomes a GEMM reduction axis zero-padded to a
+    multiple of 8 by the softmax / transpose kernels."""
+    c = q.shape[1]
+    hd = c // heads
+    if hd % 8:
+        raise ValueError("head width must be a multiple of 8 on the HIP path")
+    scale = 1.0 / math.sqrt(hd)
+    z, dev = b * heads, q.device
+    kp, qp = (skv + 7) // 8 * 8, (sq + 7) // 8 * 8
+
+    def tr(src, rows, pad):
+        """the head slices of a [B * rows, C] token matrix -> [z][hd][pad]: token axis last, zero padded to `pad`."""
+        out = torch.empty((z, hd, pad), dtype=BF16, device=dev)
+        call("mi_transpose_bf16", ptr(src), c, rows * c, hd, ptr(out), pad, heads * hd * pad, hd * pad, rows, hd, z, heads)
+        return out
+
+    scores = torch.empty((z, sq, skv), dtype=F32, device=dev)
+    _gemm(q, c, sq * c, hd, k, c, skv * c, hd, scores, skv, heads * sq * skv, sq * skv, sq, skv, hd, z, heads, alpha=scale)
+    probs = ops.softmax_fwd(scores, pad8=True)  # [z, Sq, Skv] view, pitch kp
+    del scores
+    vt = tr(v, skv, kp)  # [z, hd, kp]
+    o = torch.empty((b * sq, c), dtype=BF16, device=dev)
+    _gemm(probs, kp, heads * sq * kp, sq * kp, vt, kp, heads * hd * kp, hd * kp, o, c, sq * c, hd, sq, hd, kp, z, heads)
+    ctx.count(4 * b * sq * skv * c)
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            do = tape.take(o)
+            if do is None:
+                return
+            dp = torch.empty((z, sq, skv), dtype=F32, device=dev)
+            _gemm(do, c, sq * c, hd, v, c, skv * c, hd, dp, skv, heads * sq * skv, sq * skv, sq, skv, hd, z, heads)
+            ds = ops.softmax_bwd(probs, dp, scale)  # [z, Sq, Skv] view, pitch kp
+            del dp
+            kt = tr(k, skv, kp)
+            dq = torch.empty((b * sq, c), dtype=BF16, device=dev)
+            _gemm(ds, kp, heads * sq * kp, sq * kp, kt, kp, heads * hd * kp, hd * kp, dq, c, sq * c, hd, sq, hd, kp, z, heads)
+            tape.put(q, dq)
+
+            def tr_ss(src):  # [z][Sq][Skv] (pitch kp) -> [z][Skv][qp]
+                out = torch.empty((z, skv, qp), dtype=BF16, device=dev)
+                call("mi_transpose_bf16", ptr(src), kp, heads * sq * kp, sq * kp, ptr(out), qp, heads * skv * qp, skv * qp, sq, skv, z, heads)
+                return out
+
+            dst, qt = tr_ss(ds), tr(q, sq, qp)
+            dk = torch.empty((b * skv, c), dtype=BF16, device=dev)
+            _gemm(dst, qp, heads * skv * qp, skv * qp, qt, qp, heads * hd * qp, hd * qp, dk, c, skv * c, hd, skv, hd, qp, z, heads)
+            pt, dot = tr_ss(probs), tr(do, sq, qp)
+            dv = torch.empty((b * skv, c), dtype=BF16, device=dev)
+            _gemm(pt, qp, heads * skv * qp, skv * qp, dot, qp, heads * hd * qp, hd * qp, dv, c, skv * c, hd, skv, hd, qp, z, heads)
+            tape.put(k, dk), tape.put(v, dv)
+
+        tape.record(bwd)
+    return o
+
+
+def spatial_transformer(ctx: Ctx, x, name, context, groups, eps, heads, layers):
+    """SpatialTransformer.forward (UNet:314-342) with BasicTransformerBlock.forward (UNet:225-234) inlined:
+    GroupNorm -> 1x1 proj_in -> [self-attention, cross-attention on `context`, GEGLU feed-forward] x layers -> 1x1 proj_out + x.
+    context: bf16 [B * Sc, Cc] token matrix (or None: attn2 is a second self-attention, UNet:159); it is a constant of the step
+    (a text / label encoder is trained through its own graph)."""
+    b, d_, h_, w_, c = x.shape
+    s = d_ * h_ * w_
+    pre = name + "." if name else ""
+    st = gn(ctx, x, pre + "norm", groups, eps)
+    xn = gn_act(ctx, x, st, False)
+    one, zero = (1, 1, 1), (0, 0, 0)
+    t = _reshape(ctx, conv(ctx, xn, pre + "proj_in.conv", one, one, zero), (b * s, c))
+    sc = context.shape[0] // b if context is not None else s
+    for li in range(layers):
+        blk = f"{pre}transformer_blocks.{li}"
+        n1 = layernorm(ctx, t, blk + ".norm1")
+        a1 = blk + ".attn1"
+        o = mha(ctx, linear(ctx, n1, a1 + ".to_q", bias=False), linear(ctx, n1, a1 + ".to_k", bias=False),
+                linear(ctx, n1, a1 + ".to_v", bias=False), b, s, s, heads)
+        t = linear(ctx, o, a1 + ".to_out.0", res=t)
+        n2 = layernorm(ctx, t, blk + ".norm2")
+        a2 = blk + ".attn2"
+        kv_src, kv_grad = (context, False) if context is not None else (n2, True)
+        o = mha(ctx, linear(ctx, n2, a2 + ".to_q", bias=False), linear(ctx, kv_src, a2 + ".to_k", bias=False, need_dx=kv_grad),
+                linear(ctx, kv_src, a2 + ".to_v", bias=False, need_dx=kv_grad), b, s, sc, heads)
+        t = linear(ctx, o, a2 + ".to_out.0", res=t)
+        n3 = layernorm(ctx, t, blk + ".norm3")
+        t = linear(ctx, geglu(ctx, linear(ctx, n3, blk + ".ff.linear1")), blk + ".ff.linear2", res=t)
+    return conv(ctx, _reshape(ctx, t, (b, d_, h_, w_, c)), pre + "proj_out.conv", one, one, zero, res=x)

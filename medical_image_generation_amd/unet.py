@@ -6,8 +6,9 @@ ValueError conditions.  Forward and backward run entirely on hand-written HIP ke
 activations, fp32 accumulate / statistics / gradients); PyTorch provides memory, streams and the autograd edge.
 
 Also on the HIP path: class embeddings (`num_class_embeds`), `resblock_updown=True` (avg-pool / nearest resnet resamplers,
-UNet:640-644, 679-687) and ControlNet residual inputs (UNet:1995-2010).  Not implemented (raise NotImplementedError; never
-enabled by the reference's own configs): cross-attention conditioning, xformers flash attention.
+UNet:640-644, 679-687), ControlNet residual inputs (UNet:1995-2010) and `with_conditioning=True` (SpatialTransformer blocks:
+self-attention, cross-attention on `context`, GEGLU feed-forward, UNet:72-342; `dropout_cattn` must be 0).  Not implemented:
+xformers flash attention (`use_flash_attention=True` raises like the reference does without xformers).
 """
 from __future__ import annotations
 
@@ -77,12 +78,31 @@ class ParamSpec:
         self._add(name + ".weight", w)
         self._add(name + ".bias", b)
 
-    def linear(self, name, cin, cout, trainable=True):
+    def linear(self, name, cin, cout, trainable=True, bias=True):
         w = torch.empty(cout, cin)
         nn.init.kaiming_uniform_(w, a=math.sqrt(5))
         bound = 1 / math.sqrt(cin)
         self._add(name + ".weight", w, trainable)
-        self._add(name + ".bias", torch.empty(cout).uniform_(-bound, bound), trainable)
+        if bias:
+            self._add(name + ".bias", torch.empty(cout).uniform_(-bound, bound), trainable)
+
+    def transformer(self, name, c, cdim, layers):
+        """SpatialTransformer parameters (UNet:256-312; inner_dim == c)."""
+        name = name + "." if name else ""
+        self.norm(name + "norm", c)
+        self.conv(name + "proj_in.conv", c, c, 1)
+        for k in range(layers):
+            blk = f"{name}transformer_blocks.{k}"
+            for attn, kv in (("attn1", c), ("attn2", cdim)):  # CrossAttention (UNet:86-111): q / k / v without bias
+                self.linear(f"{blk}.{attn}.to_q", c, c, bias=False)
+                self.linear(f"{blk}.{attn}.to_k", kv, c, bias=False)
+                self.linear(f"{blk}.{attn}.to_v", kv, c, bias=False)
+                self.linear(f"{blk}.{attn}.to_out.0", c, c)
+            self.linear(f"{blk}.ff.linear1", c, 8 * c)  # monai MLPBlock(hidden c, mlp_dim 4c, act="GEGLU"), UNet:211
+            self.linear(f"{blk}.ff.linear2", 4 * c, c)
+            for n in ("norm1", "norm2", "norm3"):
+                self.norm(f"{blk}.{n}", c)
+        self.conv(name + "proj_out.conv", c, c, 1, zero=True)
 
     def norm(self, name, c):
         self._add(name + ".weight", torch.ones(c))
@@ -247,9 +267,10 @@ class DiffusionModelUNet(HipModule):
                              "`num_channels`.")
         if use_flash_attention:
             raise ValueError("use_flash_attention is True but xformers is not installed.")
-        if with_conditioning:
-            raise NotImplementedError("cross-attention conditioning is not on the HIP path yet "
-                                      "(never enabled by the reference's configs; SURVEY 8f-4)")
+        if with_conditioning and dropout_cattn > 0.0:
+            raise NotImplementedError("dropout_cattn > 0 is not on the HIP path (the reference's default is 0.0)")
+        if with_conditioning and (cross_attention_dim % 8 or any(a and n % 8 for a, n in zip(attention_levels, num_head_channels))):
+            raise ValueError("cross_attention_dim and num_head_channels must be multiples of 8 on the HIP path")
         if spatial_dims not in (2, 3):
             raise ValueError("spatial_dims must be 2 or 3")
 
@@ -259,7 +280,8 @@ class DiffusionModelUNet(HipModule):
         self.num_res_blocks = nrb = tuple(num_res_blocks)
         self.attention_levels = att = tuple(attention_levels)
         self.num_head_channels = nhc = tuple(num_head_channels)
-        self.with_conditioning = False
+        self.with_conditioning = bool(with_conditioning)
+        self.cross_attention_dim, self.transformer_num_layers = cross_attention_dim, transformer_num_layers
         self.num_class_embeds = num_class_embeds
         self.resblock_updown = bool(resblock_updown)
         # Activation checkpointing per ResnetBlock / AttentionBlock (BASELINE config 5; the reference has it in AutoencoderKL only,
@@ -287,8 +309,11 @@ class DiffusionModelUNet(HipModule):
             self._resnets.append((name, cin, cout))
 
         def attn(name, c):
-            spec.attention(name, c)
-            self._attns.append(name)
+            if with_conditioning:  # SpatialTransformer in place of AttentionBlock (UNet:1859-1860)
+                spec.transformer(name, c, cross_attention_dim, transformer_num_layers)
+            else:
+                spec.attention(name, c)
+                self._attns.append(name)
 
         spec.conv("conv_in.conv", in_channels, ch[0], kernel_sizes[0])
         spec.linear("time_embed.0", ch[0], temb)
@@ -372,14 +397,18 @@ class DiffusionModelUNet(HipModule):
         return E.checkpoint(c, run, x) if self.use_checkpointing else run(c, x)
 
     def _attention(self, c, x, name, heads):
-        run = lambda cc, xx: E.attention(cc, xx, name, self.groups, self.eps, heads)
+        if self.with_conditioning:  # heads = channels // num_head_channels (UNet:976-990)
+            run = lambda cc, xx: E.spatial_transformer(cc, xx, name, self._context, self.groups, self.eps, heads, self.transformer_num_layers)
+        else:
+            run = lambda cc, xx: E.attention(cc, xx, name, self.groups, self.eps, heads)
         return E.checkpoint(c, run, x) if self.use_checkpointing else run(c, x)
 
     def _heads(self, ch, nhc):
         return ch // nhc if nhc is not None else 1
 
-    def _run(self, c: E.Ctx, x_cl, timesteps, need_dx, class_labels=None, down_res=None, mid_res=None):
+    def _run(self, c: E.Ctx, x_cl, timesteps, need_dx, class_labels=None, down_res=None, mid_res=None, context=None):
         ch, L, sd = self.block_out_channels, len(self.block_out_channels), self.spatial_dims
+        self._context = context  # bf16 [B * Sc, Cc] token matrix of the cross-attention context (with_conditioning) or None
         a = c.arena
         dev = x_cl.device
         grad = c.tape is not None
@@ -502,7 +531,7 @@ class DiffusionModelUNet(HipModule):
     # ------------------------------------------------------------------------------------------ public forward
     def forward(self, x, timesteps, context=None, class_labels=None, down_block_additional_residuals=None,
                 mid_block_additional_residual=None):
-        if context is not None:
+        if context is not None and not self.with_conditioning:
             raise ValueError("model should have with_conditioning = True if context is provided")
         if timesteps.ndim != 1:
             raise ValueError("Timesteps should be a 1d-array")
@@ -525,9 +554,15 @@ class DiffusionModelUNet(HipModule):
         down_res = [to_cl(r) for r in down_block_additional_residuals] if down_block_additional_residuals is not None else None
         mid_res = to_cl(mid_block_additional_residual) if mid_block_additional_residual is not None else None
 
+        ctx_tokens = None
+        if context is not None:  # [B, Sc, cross_attention_dim] -> bf16 token matrix; a constant of the step (no gradient returned)
+            if context.dim() != 3 or context.shape[0] != x.shape[0] or context.shape[2] != self.cross_attention_dim:
+                raise ValueError(f"context must be [batch, tokens, {self.cross_attention_dim}], got {tuple(context.shape)}")
+            ctx_tokens = ops.cast_bf16(context.detach().to(x.device).contiguous().float().reshape(-1, context.shape[2]))
+
         def runner(c, xin, need_dx):
             x_cl = ops.to_channels_last(xin.contiguous().float())
-            y = self._run(c, x_cl, timesteps, need_dx, class_labels, down_res, mid_res)
+            y = self._run(c, x_cl, timesteps, need_dx, class_labels, down_res, mid_res, ctx_tokens)
             return (y,), {"x_cl": x_cl}
 
         grad_enabled = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters()))

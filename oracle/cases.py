@@ -45,6 +45,14 @@ UNET_CASES = {
                     attention_levels=(False, False), num_head_channels=(0, 16), norm_num_groups=8, resblock_updown=True,
                     strides=[[1, 1], [2, 2]], kernel_sizes=[[3, 3], [2, 2]], paddings=[[1, 1], [0, 0]]),
         shape=(2, 1, 16, 16), timesteps=(10, 20)),
+    # with_conditioning=True: SpatialTransformer (self-attention + cross-attention on a context + GEGLU feed-forward) in place of
+    # AttentionBlock at the attention levels (UNet:72-342); 2 transformer layers, context of 5 tokens x 16 channels
+    "unet2d_xattn": dict(
+        kwargs=dict(spatial_dims=2, in_channels=1, out_channels=1, num_res_blocks=1, num_channels=(32, 64),
+                    attention_levels=(False, True), num_head_channels=(0, 32), norm_num_groups=8, with_conditioning=True,
+                    transformer_num_layers=2, cross_attention_dim=16,
+                    strides=_iso(2, 2), kernel_sizes=[[3, 3]] * 2, paddings=[[1, 1]] * 2),
+        shape=(2, 1, 16, 16), timesteps=(5, 600), context=(2, 5, 16)),
     # ---- the BASELINE configs on their EXACT model kwargs, at sizes the reference finishes in seconds on CPU ----
     # C2 / C4: pixel-space 3D DDPM net, (32,64,128,256), 2 res-blocks, attention at the coarsest level with heads of 64
     "unet_c4": dict(

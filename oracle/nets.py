@@ -76,6 +76,28 @@ class _Builder:
         _attach(self.root, name + ".weight", torch.ones(c))
         _attach(self.root, name + ".bias", torch.zeros(c))
 
+    def linear_nobias(self, name: str, cin: int, cout: int) -> None:
+        w = torch.empty(cout, cin)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))
+        _attach(self.root, name + ".weight", w)
+
+    def transformer(self, name: str, c: int, cdim: int, layers: int) -> None:
+        """SpatialTransformer.__init__, UNet:256-312 (inner_dim == c: heads * num_head_channels)."""
+        self.norm(name + ".norm", c)
+        self.conv(name + ".proj_in.conv", c, c, 1)
+        for k in range(layers):
+            blk = f"{name}.transformer_blocks.{k}"
+            for attn, kv in (("attn1", c), ("attn2", cdim)):  # CrossAttention.__init__, UNet:86-111 (q/k/v without bias)
+                self.linear_nobias(f"{blk}.{attn}.to_q", c, c)
+                self.linear_nobias(f"{blk}.{attn}.to_k", kv, c)
+                self.linear_nobias(f"{blk}.{attn}.to_v", kv, c)
+                self.linear(f"{blk}.{attn}.to_out.0", c, c)
+            self.linear(f"{blk}.ff.linear1", c, 8 * c)  # MLPBlock(hidden c, mlp_dim 4c, GEGLU): third-party monai, UNet:211
+            self.linear(f"{blk}.ff.linear2", 4 * c, c)
+            for n in ("norm1", "norm2", "norm3"):
+                self.norm(f"{blk}.{n}", c)
+        self.conv(name + ".proj_out.conv", c, c, 1, zero=True)
+
     def attention(self, name: str, c: int) -> None:
         # AttentionBlock.__init__, UNet:377-383 / AEKL:238-244 (proj_attn exists, is never used)
         self.norm(name + ".norm", c)
@@ -114,6 +136,42 @@ def self_attention(p: dict, name: str, x: torch.Tensor, groups: int, eps: float,
     att = torch.softmax(torch.matmul(split(q), split(k).transpose(-1, -2)) * scale, dim=-1)
     o = torch.matmul(att, split(v)).permute(0, 2, 1, 3).reshape(b, s, c)
     return o.transpose(1, 2).reshape(x.shape) + x
+
+
+def cross_attention(p: dict, name: str, x: torch.Tensor, context, heads: int) -> torch.Tensor:
+    """CrossAttention.forward, UNet:156-175: x [B, S, C]; context [B, Sc, Cc] or None (self-attention)."""
+    ctx = x if context is None else context
+    q = F.linear(x, p[name + ".to_q.weight"])
+    k = F.linear(ctx, p[name + ".to_k.weight"])
+    v = F.linear(ctx, p[name + ".to_v.weight"])
+    b, s, c = q.shape
+    d = c // heads
+
+    def split(t):
+        return t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3)
+
+    att = torch.softmax(torch.matmul(split(q), split(k).transpose(-1, -2)) * (1 / math.sqrt(d)), dim=-1)
+    o = torch.matmul(att, split(v)).permute(0, 2, 1, 3).reshape(b, s, c)
+    return F.linear(o, p[name + ".to_out.0.weight"], p[name + ".to_out.0.bias"])
+
+
+def spatial_transformer(p: dict, name: str, x: torch.Tensor, context, groups: int, eps: float, heads: int, layers: int) -> torch.Tensor:
+    """SpatialTransformer.forward, UNet:314-342, with BasicTransformerBlock.forward (UNet:225-234) inlined.  The feed-forward is
+    monai's MLPBlock(act="GEGLU") (third-party; restated: linear1 -> x * gelu(gate) -> linear2)."""
+    sd = x.dim() - 2
+    c = x.shape[1]
+    h = F.group_norm(x, groups, p[name + ".norm.weight"], p[name + ".norm.bias"], eps)
+    h = _conv_nd(sd)(h, p[name + ".proj_in.conv.weight"], p[name + ".proj_in.conv.bias"])
+    t = h.reshape(x.shape[0], c, -1).transpose(1, 2)  # [B, S, C]
+    for k in range(layers):
+        blk = f"{name}.transformer_blocks.{k}"
+        ln = lambda n, v: F.layer_norm(v, (c,), p[f"{blk}.{n}.weight"], p[f"{blk}.{n}.bias"], 1e-5)
+        t = cross_attention(p, blk + ".attn1", ln("norm1", t), None, heads) + t
+        t = cross_attention(p, blk + ".attn2", ln("norm2", t), context, heads) + t
+        a, gate = F.linear(ln("norm3", t), p[blk + ".ff.linear1.weight"], p[blk + ".ff.linear1.bias"]).chunk(2, dim=-1)
+        t = F.linear(a * F.gelu(gate), p[blk + ".ff.linear2.weight"], p[blk + ".ff.linear2.bias"]) + t
+    h = t.transpose(1, 2).reshape(x.shape)
+    return _conv_nd(sd)(h, p[name + ".proj_out.conv.weight"], p[name + ".proj_out.conv.bias"]) + x
 
 
 # --------------------------------------------------------------------------- UNet
@@ -165,8 +223,6 @@ class DiffusionModelUNet(nn.Module):
             raise ValueError("num_res_blocks must be an int or have the same length as num_channels")
         if use_flash_attention:
             raise ValueError("use_flash_attention needs xformers + CUDA; not available to the oracle")
-        if with_conditioning:
-            raise NotImplementedError("cross-attention conditioning: parity unpinned (SURVEY 8f-4)")
 
         sd = self.sd = spatial_dims
         self.in_channels, self.out_channels = in_channels, out_channels
@@ -177,6 +233,7 @@ class DiffusionModelUNet(nn.Module):
         self.groups, self.eps = norm_num_groups, norm_eps
         self.resblock_updown = resblock_updown
         self.num_class_embeds = num_class_embeds
+        self.with_conditioning, self.cross_attention_dim, self.transformer_num_layers = with_conditioning, cross_attention_dim, transformer_num_layers
         self.strides, self.kernel_sizes, self.paddings = strides, kernel_sizes, paddings
         L = len(ch)
         b = _Builder(self, sd)
@@ -192,6 +249,12 @@ class DiffusionModelUNet(nn.Module):
             if cin != cout:
                 b.conv(name + ".skip_connection.conv", cin, cout, 1)
 
+        def attn_params(name, c):  # AttentionBlock, or SpatialTransformer when with_conditioning (UNet:1859-1860)
+            if with_conditioning:
+                b.transformer(name, c, cross_attention_dim, transformer_num_layers)
+            else:
+                b.attention(name, c)
+
         b.conv("conv_in.conv", in_channels, ch[0], kernel_sizes[0])
         b.linear("time_embed.0", ch[0], temb)
         b.linear("time_embed.2", temb, temb)
@@ -204,7 +267,7 @@ class DiffusionModelUNet(nn.Module):
             for j in range(nrb[i]):
                 resnet(f"down_blocks.{i}.resnets.{j}", in_c if j == 0 else out_c, out_c)
                 if att[i]:
-                    b.attention(f"down_blocks.{i}.attentions.{j}", out_c)
+                    attn_params(f"down_blocks.{i}.attentions.{j}", out_c)
             if i != L - 1:
                 if resblock_updown:
                     resnet(f"down_blocks.{i}.downsampler", out_c, out_c)
@@ -212,7 +275,7 @@ class DiffusionModelUNet(nn.Module):
                     b.conv(f"down_blocks.{i}.downsampler.op.conv", out_c, out_c, kernel_sizes[i + 1])
 
         resnet("middle_block.resnet_1", ch[-1], ch[-1])
-        b.attention("middle_block.attention", ch[-1])
+        attn_params("middle_block.attention", ch[-1])
         resnet("middle_block.resnet_2", ch[-1], ch[-1])
 
         rch = list(reversed(ch))
@@ -227,7 +290,7 @@ class DiffusionModelUNet(nn.Module):
                 skip_c = in_c if j == n - 1 else out_c
                 resnet(f"up_blocks.{i}.resnets.{j}", (prev if j == 0 else out_c) + skip_c, out_c)
                 if ratt[i]:
-                    b.attention(f"up_blocks.{i}.attentions.{j}", out_c)
+                    attn_params(f"up_blocks.{i}.attentions.{j}", out_c)
             if i != L - 1:
                 if resblock_updown:
                     resnet(f"up_blocks.{i}.upsampler", out_c, out_c)
@@ -272,8 +335,13 @@ class DiffusionModelUNet(nn.Module):
             if class_labels is None:
                 raise ValueError("class_labels should be provided when num_class_embeds > 0")
             emb = emb + p["class_embedding.weight"][class_labels].to(x.dtype)
-        if context is not None:
+        if context is not None and not self.with_conditioning:
             raise ValueError("model should have with_conditioning = True if context is provided")
+
+        def attend(name, h, c, nhc):
+            if self.with_conditioning:  # SpatialTransformer(num_attention_heads = c // num_head_channels), UNet:976-990
+                return spatial_transformer(p, name, h, context, self.groups, self.eps, c // nhc, self.transformer_num_layers)
+            return self_attention(p, name, h, self.groups, self.eps, self._heads(c, nhc))
 
         h = self._conv(p, "conv_in.conv", x, self.strides[0], self.paddings[0])
         skips = [h]
@@ -281,8 +349,7 @@ class DiffusionModelUNet(nn.Module):
             for j in range(self.num_res_blocks[i]):
                 h = self._resnet(p, f"down_blocks.{i}.resnets.{j}", h, emb)
                 if self.attention_levels[i]:
-                    h = self_attention(p, f"down_blocks.{i}.attentions.{j}", h, self.groups, self.eps,
-                                       self._heads(ch[i], self.num_head_channels[i]))
+                    h = attend(f"down_blocks.{i}.attentions.{j}", h, ch[i], self.num_head_channels[i])
                 skips.append(h)
             if i != L - 1:
                 if self.resblock_updown:
@@ -295,8 +362,7 @@ class DiffusionModelUNet(nn.Module):
             skips = [s + r for s, r in zip(skips, down_block_additional_residuals)]
 
         h = self._resnet(p, "middle_block.resnet_1", h, emb)
-        h = self_attention(p, "middle_block.attention", h, self.groups, self.eps,
-                           self._heads(ch[-1], self.num_head_channels[-1]))
+        h = attend("middle_block.attention", h, ch[-1], self.num_head_channels[-1])
         h = self._resnet(p, "middle_block.resnet_2", h, emb)
         if mid_block_additional_residual is not None:
             h = h + mid_block_additional_residual
@@ -311,8 +377,7 @@ class DiffusionModelUNet(nn.Module):
                 h = torch.cat([h, skips.pop()], dim=1)
                 h = self._resnet(p, f"up_blocks.{i}.resnets.{j}", h, emb)
                 if ratt[i]:
-                    h = self_attention(p, f"up_blocks.{i}.attentions.{j}", h, self.groups, self.eps,
-                                       self._heads(rch[i], rnhc[i]))
+                    h = attend(f"up_blocks.{i}.attentions.{j}", h, rch[i], rnhc[i])
             if i != L - 1:
                 if self.resblock_updown:
                     h = self._resnet(p, f"up_blocks.{i}.upsampler", h, emb, "up", rstr[i])

@@ -82,6 +82,8 @@ def unet_case(ru, name):
     extra = {}
     if "class_labels" in c:
         extra["class_labels"] = torch.tensor(c["class_labels"])
+    if "context" in c:
+        extra["context"] = synth.tensor(cases.SEED, "context", c["context"])
     pred = net(x, t, **extra)
     gy = synth.tensor(cases.SEED, "grad_out", pred.shape)
     xg = x.clone().requires_grad_(True)

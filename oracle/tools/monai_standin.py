@@ -9,8 +9,11 @@ files import exactly four symbols from it (UNet:40-42, AEKL:21-22).  With
 `nn.Conv{1,2,3}d`; that published behaviour is restated here.  Everything else in
 the golden vectors comes from the reference's own code running unmodified.
 
-Not restated (=> parity unpinned there, documented in DESIGN.md): `MLPBlock`
-(cross-attention GEGLU path) and transposed `Convolution`.
+`MLPBlock(hidden_size, mlp_dim, act="GEGLU", dropout_rate)` -- the feed-forward of the cross-attention path (UNet:211) -- is
+restated from monai's published behaviour as well (linear1: hidden -> 2 * mlp_dim, GEGLU: x, gate = chunk(2, -1); x * gelu(gate),
+dropout, linear2: mlp_dim -> hidden, dropout; children named `linear1`, `linear2`).  monai's source is not under /root/reference,
+so that ONE block of the cross-attention goldens is PARITY UNPINNED (documented in DESIGN.md); attention, LayerNorm, projections and
+wiring are the reference's own code.  Not restated: transposed `Convolution`.
 """
 from __future__ import annotations
 
@@ -48,9 +51,19 @@ def ensure_tuple_rep(value, dim):
     return (value,) * dim
 
 
-class _Unavailable:
-    def __init__(self, *a, **k):
-        raise NotImplementedError("monai.networks.blocks.MLPBlock is not restated (cross-attention path)")
+class MLPBlock(nn.Module):
+    def __init__(self, hidden_size, mlp_dim, dropout_rate=0.0, act="GELU", dropout_mode="vit"):
+        super().__init__()
+        if act != "GEGLU":
+            raise NotImplementedError("stand-in covers MLPBlock(act='GEGLU') only (the reference's call, UNet:211)")
+        self.linear1 = nn.Linear(hidden_size, mlp_dim * 2)
+        self.linear2 = nn.Linear(mlp_dim, hidden_size)
+        self.drop1, self.drop2 = nn.Dropout(dropout_rate), nn.Dropout(dropout_rate)
+
+    def forward(self, x):
+        x, gate = self.linear1(x).chunk(2, dim=-1)
+        x = self.drop1(x * nn.functional.gelu(gate))
+        return self.drop2(self.linear2(x))
 
 
 def install() -> None:
@@ -66,6 +79,6 @@ def install() -> None:
 
     mk("monai"), mk("monai.networks"), mk("monai.networks.layers")
     blocks, fac, utils = mk("monai.networks.blocks"), mk("monai.networks.layers.factories"), mk("monai.utils")
-    blocks.Convolution, blocks.MLPBlock = Convolution, _Unavailable
+    blocks.Convolution, blocks.MLPBlock = Convolution, MLPBlock
     fac.Pool = _PoolFactory()
     utils.ensure_tuple_rep = ensure_tuple_rep

@@ -68,6 +68,8 @@ def test_unet_matches_reference(golden, name):
     net.load_state_dict(sd)  # strict: key set and shapes identical to the reference's state_dict
     x = synth.tensor(S, "x", c["shape"]).requires_grad_(True)
     extra = {"class_labels": torch.tensor(c["class_labels"])} if "class_labels" in c else {}
+    if "context" in c:
+        extra["context"] = synth.tensor(S, "context", c["context"])
     pred = net(x, torch.tensor(c["timesteps"]), **extra)
     _close(pred.detach(), g["pred"])
     pred.backward(synth.tensor(S, "grad_out", pred.shape))

@@ -17,7 +17,8 @@ pytestmark = pytest.mark.gpu
 S = cases.SEED
 # the last four are the BASELINE configs on their exact kwargs (C2/C4 net at 32^3 x 2 and at 24x40x48; C3b and C5 latent nets)
 # `unet2d_updown`: resblock_updown=True (avg-pool / nearest resnet resamplers)
-HIP_CASES = ["unet3d", "unet_ldm", "unet_c1", "unet_c4", "unet_c4_np2", "unet_c3b", "unet_c5", "unet2d_updown"]
+# `unet2d_xattn`: with_conditioning=True (SpatialTransformer: self- + cross-attention on a context, GEGLU feed-forward)
+HIP_CASES = ["unet3d", "unet_ldm", "unet_c1", "unet_c4", "unet_c4_np2", "unet_c3b", "unet_c5", "unet2d_updown", "unet2d_xattn"]
 
 
 def rel_l2(a, b):
@@ -44,14 +45,15 @@ def test_unet_forward_backward_matches_reference(golden, name):
     t = torch.tensor(c["timesteps"])
     gy = synth.tensor(S, "grad_out", g["pred"].shape)
     xd = x.cuda().requires_grad_(True)
-    pred = net(xd, t.cuda())
+    extra = {"context": synth.tensor(S, "context", c["context"])} if "context" in c else {}
+    pred = net(xd, t.cuda(), **{k: v.cuda() for k, v in extra.items()})
     assert pred.dtype == torch.float32 and pred.shape == g["pred"].shape
     e_pred = rel_l2(pred.detach().cpu(), g["pred"])
     pred.backward(gy.cuda())
     e_dx = rel_l2(xd.grad.cpu(), g["dx"])
     # oracle gradients (full tensors) for the per-parameter comparison
     xr = x.clone().requires_grad_(True)
-    ref(xr, t).backward(gy)
+    ref(xr, t, **extra).backward(gy)
     rg = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
     hg = {n: p.grad.cpu() for n, p in net.named_parameters() if p.grad is not None}
     assert sorted(hg) == sorted(rg) == meta["grad_names"].split("\n")  # proj_attn.* grad-less on both sides

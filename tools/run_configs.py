@@ -1,5 +1,8 @@
 """Run the other BASELINE.json configs through the fused HIP trainer and report ms/step (sanity + scale check).
-usage: python tools/run_configs.py c2|c3b|c5 [steps]"""
+usage: python tools/run_configs.py c2|c3a|c3b|c3b_ldm|c5|c5_ckpt [steps]
+  c3b_ldm: the latent-diffusion step as train_ldm.py runs it -- no-grad AutoencoderKL.encode_stage_2_inputs of the 4 x 128^3 images
+           inside the step (LDMTrainer), then the C3b UNet step on the scaled latents
+  c5_ckpt: C5 with per-block activation checkpointing (BASELINE configs[4])"""
 import json
 import math
 import os
@@ -55,7 +58,9 @@ if which == "c2":   # 3D DDPM 96^3, batch 2 (BASELINE configs[1])
               attention_levels=(False, False, False, True), num_head_channels=(0, 0, 0, 64), norm_num_groups=32,
               strides=iso(4), kernel_sizes=[[3] * 3] * 4, paddings=[[1] * 3] * 4)
     shape, vox_per_sample = (2, 1, 96, 96, 96), 96 ** 3
-elif which in ("c3b", "c5"):  # latent UNet the reference's planner emits (CFG:876-902); C5: 40^3 latents (160^3 patch), +1 label channel
+elif which in ("c3b", "c5", "c3b_ldm", "c5_ckpt"):  # latent UNet the reference's planner emits (CFG:876-902); C5: 40^3 latents (160^3 patch), +1 label channel
+    ldm, ckpt = which == "c3b_ldm", which == "c5_ckpt"
+    which = {"c3b_ldm": "c3b", "c5_ckpt": "c5"}.get(which, which)
     cin = 8 if which == "c3b" else 9
     kw = dict(spatial_dims=3, in_channels=cin, out_channels=8 if which == "c3b" else 9, num_res_blocks=2, num_channels=[256, 512, 768],
               attention_levels=[False, True, True], num_head_channels=[0, 512, 768], norm_num_groups=32,
@@ -69,11 +74,25 @@ for p in net.parameters():
     if float(p.detach().abs().max()) == 0:
         torch.nn.init.normal_(p, std=0.02)
 net = net.to(dev)
-tr = DDPMTrainer(net, lr=2e-5)
-x0 = torch.rand(shape, device=dev)
+ldm, ckpt = globals().get("ldm", False), globals().get("ckpt", False)
+net.use_checkpointing = ckpt
 noise = torch.randn(shape, device=dev)
 t = torch.randint(0, 1000, (shape[0],), device=dev)
-tr.capture(x0, noise, t)
+if ldm:
+    from medical_image_generation_amd.autoencoderkl import AutoencoderKL
+    from medical_image_generation_amd.trainer import LDMTrainer
+    down = [[[1] * 3, [3] * 3, [1] * 3], [[2] * 3, [3] * 3, [1] * 3], [[2] * 3, [3] * 3, [1] * 3]]
+    ae = AutoencoderKL(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=8, num_res_blocks=2, num_channels=[32, 64, 128],
+                       attention_levels=[False] * 3, norm_num_groups=16, with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False,
+                       downsample_parameters=down, upsample_parameters=list(reversed(down))[:-1]).to(dev)
+    tr = LDMTrainer(net, ae, lr=2e-5)
+    images, eps = torch.rand((4, 1, 128, 128, 128), device=dev), torch.randn(shape, device=dev)
+    tr.estimate_scale_factor(images, eps)
+    tr.capture(images, eps, noise, t)
+else:
+    tr = DDPMTrainer(net, lr=2e-5)
+    x0 = torch.rand(shape, device=dev)
+    tr.capture(x0, noise, t)
 for _ in range(2):
     tr.step_graph()
 torch.cuda.synchronize()
@@ -88,6 +107,7 @@ net._run(c, torch.zeros(dims, dtype=torch.bfloat16, device=dev), t, need_dx=Fals
 c.tape.fns.clear()
 fl = c.flops_fwd + c.flops_bwd
 assert math.isfinite(float(loss)), "non-finite loss: not a measurement"
+which = which + ("_ldm" if ldm else "") + ("_ckpt" if ckpt else "")
 print(json.dumps({"config": which, "ms_per_step": dt * 1e3, "voxels_per_s": shape[0] * vox_per_sample / dt, "loss": float(loss),
                   "params": sum(p.numel() for p in net.parameters()), "model_flops_per_step": fl, "mfma_frac": fl / dt / 2.5e15,
                   "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
