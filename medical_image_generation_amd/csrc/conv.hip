@@ -424,7 +424,7 @@ struct WgradArgs {
   const bf16* dy; int dy_cs;
   unsigned dy_bytes;  // size of dy for its buffer descriptor (LDS-DMA kernel)
   int nbuf;           // LDS-DMA kernel: image ring depth (2; 4 for 1x1 pairs)
-  float* cs_part;     // [nsplit][N][Cout] per-workgroup column sums (tap pairs): plain stores, folded by k_cs_reduce -- 256 workgroups
+  float* cs_part;     // [nsplit][N][Cout] per-workgroup column sums (tap pairs): plain stores, folded by cs_reduce_block (trailing blocks of the reduce launch) -- 256 workgroups
                       // adding to the same 128-byte line with atomics serialise for tens of microseconds
   float* part;        // [nsplit][npairs][MAXTAPS? -> ntaps_of_pair][32][32] laid out by pair_off
   const int* pair_off;  // [npairs] float offset of the pair's slab inside one split's partial
@@ -1162,6 +1162,38 @@ __global__ void __launch_bounds__(256) k_pack_groups(const PackGroup* __restrict
   }
 }
 
+// colsum[n * stride + co] += sum_split cs_part[split][n][co]   (stride 0: one row for the whole batch); block = 32 channels x 8 split groups.
+// Rides as extra trailing blocks of the weight-gradient reduce launch (one launch per conv instead of two: ~50 launches of a
+// 5 us latency-bound kernel per step).  part == nullptr: none.
+struct CsReduce {
+  const float* part;
+  int nsplit, N, Cout;
+  float* out;
+  int stride;
+  int nbx;  // blocks along the channel axis; the N images are the slow index
+};
+__device__ __forceinline__ void cs_reduce_block(const CsReduce& c, int b) {
+  __shared__ float cs_red[8][32];
+  const int co = (b % c.nbx) * 32 + (threadIdx.x & 31), n = b / c.nbx, kg = threadIdx.x >> 5;
+  float s0 = 0.f, s1 = 0.f;
+  if (co < c.Cout) {
+    int k = kg;
+    for (; k + 8 < c.nsplit; k += 16) {
+      s0 += c.part[((int64_t)k * c.N + n) * c.Cout + co];
+      s1 += c.part[((int64_t)(k + 8) * c.N + n) * c.Cout + co];
+    }
+    if (k < c.nsplit) s0 += c.part[((int64_t)k * c.N + n) * c.Cout + co];
+  }
+  cs_red[kg][threadIdx.x & 31] = s0 + s1;
+  __syncthreads();
+  if (kg == 0 && co < c.Cout) {
+    const int l = threadIdx.x;
+    const float v = ((cs_red[0][l] + cs_red[1][l]) + (cs_red[2][l] + cs_red[3][l])) + ((cs_red[4][l] + cs_red[5][l]) + (cs_red[6][l] + cs_red[7][l]));
+    if (c.stride == 0) atomicAdd(c.out + co, v);  // N rows fold into one
+    else c.out[(int64_t)n * c.stride + co] += v;
+  }
+}
+
 // dW[co][ci][tap] += sum_split part[split][pair][ti][co_l][ci_l];  uitems[(pair, ti)] = {src_tap, co0, ci0, _}
 // block = (256 / KG) elements x KG split groups: each thread sums nsplit/KG slabs with 4 independent loads in flight, LDS folds
 // the groups.  (One thread per element walking all 256 slabs serially is pure load latency; with few slabs -- wide layers --
@@ -1169,9 +1201,10 @@ __global__ void __launch_bounds__(256) k_pack_groups(const PackGroup* __restrict
 template <int KG>
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, int64_t split_stride, int nsplit,
                                                       const int* __restrict__ uitems, int nitems, float* __restrict__ dw, int Co_t,
-                                                      int Ci_t, int KT) {
+                                                      int Ci_t, int KT, CsReduce cs, int nmain) {
   constexpr int EL = 256 / KG, BPI = 1024 / EL;  // elements per block, blocks per 32x32 item
   __shared__ float red[KG][EL];
+  if ((int)blockIdx.x >= nmain) { cs_reduce_block(cs, blockIdx.x - nmain); return; }  // whole block: the column-sum fold
   const int item = blockIdx.x / BPI, l = threadIdx.x % EL, e = (blockIdx.x % BPI) * EL + l, kg = threadIdx.x / EL;
   const float* p = part + (int64_t)item * 1024 + e;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -1201,9 +1234,10 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 // its taps: the slab sums go through LDS and land in dw as one contiguous run of 32 * KT floats.
 __global__ void __launch_bounds__(256) k_wgrad_reduce_rows(const float* __restrict__ part, int64_t split_stride, int nsplit,
                                                            const int* __restrict__ uitems, const int* __restrict__ pair_off, int npairs,
-                                                           float* __restrict__ dw, int Co_t, int Ci_t, int KT) {
+                                                           float* __restrict__ dw, int Co_t, int Ci_t, int KT, CsReduce cs, int nmain) {
   __shared__ float sm[32][33];   // [ci_l][tap]  (KT <= 32)
   __shared__ unsigned present;   // taps this pair owns (strided convs split the taps over several pairs)
+  if ((int)blockIdx.x >= nmain) { cs_reduce_block(cs, blockIdx.x - nmain); return; }  // whole block: the column-sum fold
   const int pair = blockIdx.x >> 5, co_l = blockIdx.x & 31;
   const int off = pair_off[pair];
   const int nt = (int)(((pair + 1 < npairs ? (int64_t)pair_off[pair + 1] : split_stride) - off) >> 10);
@@ -1240,41 +1274,24 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce_rows(const float* __restri
 }
 
 int env_int(const char* name, int dflt);
+// cs: the conv's column-sum partials to fold in the same launch (cs.part == nullptr: none)
 inline void launch_wgrad_reduce(const float* part, int64_t split_stride, int nsplit, const int* uitems, int nitems, float* dw, int Co_t, int Ci_t,
-                                int KT, const int* pair_off, int npairs, hipStream_t st) {
+                                int KT, const int* pair_off, int npairs, CsReduce cs, hipStream_t st) {
   static const int rows_kernel = env_int("MI_WGRAD_REDUCE_ROWS", 1);
+  cs.nbx = (cs.Cout + 31) / 32;
+  const int extra = cs.part ? cs.nbx * cs.N : 0;
   if (nsplit >= 32)
-    hipLaunchKernelGGL(k_wgrad_reduce<8>, dim3(nitems * 32), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT);
+    hipLaunchKernelGGL(k_wgrad_reduce<8>, dim3(nitems * 32 + extra), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT,
+                       cs, nitems * 32);
   else if (rows_kernel && KT <= 32 && npairs >= 8)
-    hipLaunchKernelGGL(k_wgrad_reduce_rows, dim3(npairs * 32), dim3(256), 0, st, part, split_stride, nsplit, uitems, pair_off, npairs, dw, Co_t,
-                       Ci_t, KT);
+    hipLaunchKernelGGL(k_wgrad_reduce_rows, dim3(npairs * 32 + extra), dim3(256), 0, st, part, split_stride, nsplit, uitems, pair_off, npairs, dw,
+                       Co_t, Ci_t, KT, cs, npairs * 32);
   else if (nsplit >= 8)
-    hipLaunchKernelGGL(k_wgrad_reduce<4>, dim3(nitems * 16), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT);
+    hipLaunchKernelGGL(k_wgrad_reduce<4>, dim3(nitems * 16 + extra), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT,
+                       cs, nitems * 16);
   else
-    hipLaunchKernelGGL(k_wgrad_reduce<1>, dim3(nitems * 4), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT);
-}
-
-// colsum[n * stride + co] += sum_split cs_part[split][n][co]   (stride 0: one row for the whole batch); block = 32 channels x 8 split groups
-__global__ void __launch_bounds__(256) k_cs_reduce(const float* __restrict__ part, int nsplit, int N, int Cout, float* __restrict__ out, int stride) {
-  __shared__ float red[8][32];
-  const int co = blockIdx.x * 32 + (threadIdx.x & 31), n = blockIdx.y, kg = threadIdx.x >> 5;
-  float s0 = 0.f, s1 = 0.f;
-  if (co < Cout) {
-    int k = kg;
-    for (; k + 8 < nsplit; k += 16) {
-      s0 += part[((int64_t)k * N + n) * Cout + co];
-      s1 += part[((int64_t)(k + 8) * N + n) * Cout + co];
-    }
-    if (k < nsplit) s0 += part[((int64_t)k * N + n) * Cout + co];
-  }
-  red[kg][threadIdx.x & 31] = s0 + s1;
-  __syncthreads();
-  if (kg == 0 && co < Cout) {
-    const int l = threadIdx.x;
-    const float v = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) + ((red[4][l] + red[5][l]) + (red[6][l] + red[7][l]));
-    if (stride == 0) atomicAdd(out + co, v);  // N rows fold into one
-    else out[(int64_t)n * stride + co] += v;
-  }
+    hipLaunchKernelGGL(k_wgrad_reduce<1>, dim3(nitems * 4 + extra), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT,
+                       cs, nitems * 4);
 }
 
 // ------------------------------------------------------------------------------------------------ host-side plan
@@ -1336,6 +1353,7 @@ struct mi_conv_plan {
   // kernels copy the master weight into d_c1w
   bool c1_in = false, c1_out = false, c1_packed = false;
   float* d_c1w = nullptr;
+  float* d_c1part = nullptr;  // per-workgroup slabs of the single-channel weight-gradient kernel (conv_c1.hip)
   bool v27_fwd = false, v27_dg = false;  // forward / data gradient run on conv27.hip (LDS-DMA kernel); weights packed with perm16
   bool v11_fwd = false, v11_dg = false;  // 1x1x1: forward / data gradient run on conv1x1.hip (streaming GEMM); weights packed with perm16
 };
@@ -1541,6 +1559,7 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
     if (P->c1_in || P->c1_out) {
       const int C = P->c1_in ? Cout : Cin;
       if (hipMalloc((void**)&P->d_c1w, (size_t)27 * C * 4) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
+      if (hipMalloc((void**)&P->d_c1part, (size_t)mi_c1_wgrad_scratch_floats(C) * 4) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
     }
   }
   const bool geo27 = P->full27 && P->g_fwd.TD == 4 && P->g_fwd.TH == 8 && P->g_fwd.TW == 8;
@@ -1603,6 +1622,7 @@ int mi_conv_plan_destroy(mi_conv_plan* P) {
   if (P->d_part) (void)hipFree(P->d_part);
   if (P->d_cspart) (void)hipFree(P->d_cspart);
   if (P->d_c1w) (void)hipFree(P->d_c1w);
+  if (P->d_c1part) (void)hipFree(P->d_c1part);
   if (P->d_xs) (void)hipFree(P->d_xs);
   if (P->d_dxs) (void)hipFree(P->d_dxs);
   delete P;
@@ -1825,6 +1845,13 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
     int e = mi_launch_wgrad1x1(x, x_cs, P->Cin, dy, dy_cs, P->Cout, P->N, (int64_t)P->Di * P->Hi * P->Wi, dw, dy_colsum, dy_colsum_stride, st);
     if (e != MI_ERR_UNSUPPORTED) return e;
   }
+  static const int use_c1w = env_int("MI_C1_WGRAD", 1);
+  if (use_c1w && (P->c1_in || P->c1_out) && P->d_c1part && !scale_shift && !(dy_colsum && dy_colsum_stride != 0)) {
+    // one channel on one side: a streaming kernel with the 27 taps as the GEMM's N axis (conv_c1.hip) instead of padding that side to 32
+    int e = P->c1_in ? mi_launch_c1_wgrad(dy, dy_cs, x, x_cs, dw, dy_colsum, nullptr, P->d_c1part, P->N, P->Di, P->Hi, P->Wi, P->Cout, 0, st)
+                     : mi_launch_c1_wgrad(x, x_cs, dy, dy_cs, dw, nullptr, dy_colsum, P->d_c1part, P->N, P->Di, P->Hi, P->Wi, P->Cin, 1, st);
+    if (e != MI_ERR_UNSUPPORTED) return e;
+  }
   WgradArgs w;
   memset(&w, 0, sizeof(w));
   ConvArgs& a = w.c;
@@ -1907,10 +1934,8 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
       if (geo3) hipLaunchKernelGGL(k_conv_wgrad2<true>, grid, dim3(768), lds2, st, w);
       else hipLaunchKernelGGL(k_conv_wgrad2<false>, grid, dim3(768), lds2, st, w);
       launch_wgrad_reduce(P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT, P->d_pair_off,
-                          P->wg.ny * P->wg.nchunks, st);
-      if (w.cs_part)
-        hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 31) / 32, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
-                           dy_colsum_stride);
+                          P->wg.ny * P->wg.nchunks,
+                          CsReduce{w.cs_part ? P->d_cspart : nullptr, P->wg_nsplit, P->N, P->Cout, dy_colsum, dy_colsum_stride, 0}, st);
       MI_CHECK_LAUNCH();
       return 0;
     }
@@ -1926,10 +1951,8 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
 #undef MI_LAUNCH_WG
 #undef MI_LAUNCH_WG_G
   launch_wgrad_reduce(P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT, P->d_pair_off,
-                          P->wg.ny * P->wg.nchunks, st);
-  if (w.cs_part)
-    hipLaunchKernelGGL(k_cs_reduce, dim3((P->Cout + 31) / 32, P->N), dim3(256), 0, st, P->d_cspart, P->wg_nsplit, P->N, P->Cout, dy_colsum,
-                       dy_colsum_stride);
+                      P->wg.ny * P->wg.nchunks, CsReduce{w.cs_part ? P->d_cspart : nullptr, P->wg_nsplit, P->N, P->Cout, dy_colsum, dy_colsum_stride, 0},
+                      st);
   MI_CHECK_LAUNCH();
   return 0;
 }

@@ -4,7 +4,10 @@
 //   k_c1_expand  : y[v][c]  = a[c] + sum_t s[v + t] W[c][t]          forward of 1 -> C, and data gradient of C -> 1 (taps flipped)
 //   k_c1_reduce  : y[v]     = a    + sum_t sum_c x[v + t][c] W[c][t]  forward of C -> 1:  Y[u][t] = x[u][:] . W[:][t] on the MFMA for
 //                                                                    the tile + halo, then 27 shifted LDS reads per output voxel
-// (Weight gradients stay on the table-driven MFMA kernel: a VALU formulation needs 216 accumulators per thread and measured slower.)
+//   k_c1_wgrad   : dW[c][t] += sum_v m[v][c] s[v +- t]   weight gradient of both (m = the C-channel tensor, s = the single-channel one):
+//                  D[c][t] = M^T[c][vox] B[vox][t] on the MFMA with the 27 taps as the N axis; the "im2col" B fragment is gathered from a
+//                  600-voxel LDS halo of s.  One HBM pass over m (the table-driven MFMA kernel padded the 1-channel side to 32: 199 us
+//                  per call at 128^3 for a 134 MB read).
 // W is the fp32 master weight in torch layout ([C][1][27] or [1][C][27]: index c * 27 + t either way) read through the scalar cache.
 #include "common.h"
 #include "conv_common.h"
@@ -153,6 +156,140 @@ __global__ void __launch_bounds__(256) k_c1_reduce(C1Args a) {
   a.y[((((int64_t)n * a.D + z) * a.H + yy) * a.W + x) * a.y_cs] = f2bf(o);
 }
 
+// ---------------------------------------------------------------------------------------------- weight gradient of both
+// dW[c][t] += sum_v m[v][c] * s[v + d(t)],  d(t) = tap offset (FLIP: -offset: the C -> 1 conv, where m = x and s = dy);
+// column 27 of the product is m against a column of ones: sum_v m[v][c] (the bias gradient of the 1 -> C conv);
+// sum_v s[v] (the bias gradient of the C -> 1 conv) is reduced on the side.  Persistent workgroups: 4 waves, wave w owns d-slice w
+// of every 4x8x8 tile (4 k-steps of 16 voxels = 2 rows of 8), accumulators live across the workgroup's tiles; per-workgroup slabs
+// [C x 32 + 1] fp32 are folded by k_c1_wgrad_reduce (512 workgroups adding into the same 1 K addresses with atomics serialise).
+struct C1WgArgs {
+  int N, D, H, W, C;
+  const bf16* m; int m_cs;   // C-channel tensor
+  const bf16* s; int s_cs;   // single-channel tensor
+  float* part;               // [gridDim.x][NCB * 1024 + 32] slabs
+  int ntiles, flip;
+};
+// Everything a wave touches in the loop is wave-private (its d-slice of m: 64 voxels x NCB*32 channels, and the 3 halo slices of s
+// it needs), so there is no barrier in the loop (LDS operations of one wave complete in order) and the four waves drift apart,
+// which is what hides the HBM latency; the next tile's loads are issued before the current tile's MFMAs.
+template <int NCB>
+__global__ void __launch_bounds__(256) k_c1_wgrad(C1WgArgs a) {
+  constexpr int PITCH = NCB * 64, MT = 64 * PITCH, HS = 3 * kHH * kHW, HSB = (HS * 2 + 15) / 16 * 16, WV = 2 * MT + 2 * HSB;
+  constexpr int PVMAX = NCB * 4;  // 16-byte pieces per voxel
+  extern __shared__ __attribute__((aligned(16))) char c1w_lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, t = lane & 31, h = lane >> 5;
+  char* my = c1w_lds + wave * WV;
+  const int tw = (a.W + kTW - 1) / kTW, th = (a.H + kTH - 1) / kTH, td = (a.D + kTD - 1) / kTD;
+  const int PV = a.C >> 3;
+  const int tt = a.flip ? 26 - t : t;  // tap of this lane's B column (27 = ones, 28.. = zeros)
+  const int kd = tt / 9, kh = (tt / 3) % 3, kw = tt % 3;
+  for (int i = lane; i < 2 * MT / 16; i += 64) ((u32x4*)my)[i] = u32x4{0u, 0u, 0u, 0u};  // channels >= C of a ragged C stay zero
+  f32x16 acc[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[cb][e] = 0.f;
+  float s_acc = 0.f;
+
+  u32x4 mreg[PVMAX];
+  bf16 sreg[5];
+  auto issue = [&](int tile) {  // this wave's loads of `tile`: m pieces (coalesced: consecutive lanes = consecutive 16 bytes) and s halo
+    int r = tile;
+    const int tx = r % tw; r /= tw;
+    const int ty = r % th; r /= th;
+    const int tz = r % td, n = r / td;
+    const int z = tz * kTD + wave, y0 = ty * kTH, x0 = tx * kTW;
+    const bf16* mn = a.m + (int64_t)n * a.D * a.H * a.W * a.m_cs;
+    const bf16* sn = a.s + (int64_t)n * a.D * a.H * a.W * a.s_cs;
+#pragma unroll
+    for (int i = 0; i < PVMAX; ++i) {
+      const int idx = i * 64 + lane, v = idx / PV, p = idx - v * PV;
+      const int y = y0 + (v >> 3), x = x0 + (v & 7);
+      const bool in = i < PV && v < 64 && z < a.D && y < a.H && x < a.W;
+      mreg[i] = in ? *(const u32x4*)(mn + (((int64_t)z * a.H + y) * a.W + x) * a.m_cs + p * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int hi = i * 64 + lane;  // halo index inside this wave's 3 slices
+      const int hx = hi % kHW, hy = (hi / kHW) % kHH, hz = hi / (kHW * kHH);
+      const int zz = z + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+      const bool in = hi < HS && (unsigned)zz < (unsigned)a.D && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      sreg[i] = in ? sn[(((int64_t)zz * a.H + yy) * a.W + xx) * a.s_cs] : f2bf(0.f);
+    }
+  };
+  int tile = blockIdx.x, buf = 0;
+  if (tile < a.ntiles) issue(tile);
+  for (; tile < a.ntiles; tile += gridDim.x, buf ^= 1) {
+    char* mt = my + buf * MT;
+    bf16* sh = (bf16*)(my + 2 * MT + buf * HSB);
+#pragma unroll
+    for (int i = 0; i < PVMAX; ++i) {
+      const int idx = i * 64 + lane, v = idx / PV, p = idx - v * PV;
+      if (i < PV && v < 64) *(u32x4*)(mt + v * PITCH + p * 16) = mreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int hi = i * 64 + lane;
+      if (hi < HS) {
+        sh[hi] = sreg[i];
+        const int hx = hi % kHW, hy = (hi / kHW) % kHH, hz = hi / (kHW * kHH);
+        if (hz == 1 && hy >= 1 && hy <= kTH && hx >= 1 && hx <= kTW) s_acc += bf2f(sreg[i]);  // this wave's own d-slice
+      }
+    }
+    if (tile + (int)gridDim.x < a.ntiles) issue(tile + gridDim.x);  // in flight under this tile's MFMAs
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // k-step: 16 voxels = (row 2q + h, col j), j = 0..7
+      const int v0 = (2 * q + h) * 8;
+      bf16x8 bfr;
+      const int hb = (kd * kHH + 2 * q + h + kh) * kHW + kw;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bfr[j] = t < 27 ? sh[hb + j] : (t == 27 ? f2bf(1.f) : f2bf(0.f));
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        bf16x8 af;  // A[row c = cb*32 + t][k = 8h + j] = m[voxel v0 + j][c]
+#pragma unroll
+        for (int j = 0; j < 8; ++j) af[j] = *(const bf16*)(mt + (v0 + j) * PITCH + (cb * 32 + t) * 2);
+        acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[cb], 0, 0, 0);
+      }
+    }
+  }
+  // fold the 4 waves through LDS (the tile buffers are dead), write this workgroup's slab: part[c * 32 + t]
+  __syncthreads();
+  float* red = (float*)c1w_lds;  // [4][NCB * 1024] + [4]
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[wave * NCB * 1024 + cb * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * h) * 32 + t] = acc[cb][e];
+  s_acc = wave_sum(s_acc);
+  if (lane == 0) red[4 * NCB * 1024 + wave] = s_acc;
+  __syncthreads();
+  float* out = a.part + (int64_t)blockIdx.x * (NCB * 1024 + 32);
+  for (int i = threadIdx.x; i < NCB * 1024; i += 256)
+    out[i] = (red[i] + red[NCB * 1024 + i]) + (red[2 * NCB * 1024 + i] + red[3 * NCB * 1024 + i]);
+  if (threadIdx.x == 0) out[NCB * 1024] = (red[4 * NCB * 1024] + red[4 * NCB * 1024 + 1]) + (red[4 * NCB * 1024 + 2] + red[4 * NCB * 1024 + 3]);
+}
+// dw[c][t] += sum_slabs part[c * 32 + t] (t < 27);  colsum_m[c] += column 27;  colsum_s[0] += the s sums
+__global__ void __launch_bounds__(256) k_c1_wgrad_reduce(const float* __restrict__ part, int nslab, int slab, int C, float* __restrict__ dw,
+                                                         float* __restrict__ colsum_m, float* __restrict__ colsum_s) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i > C * 32) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int k = 0;
+  const int idx = i < C * 32 ? i : slab - 32;
+  for (; k + 3 < nslab; k += 4) {
+    s0 += part[(int64_t)k * slab + idx];
+    s1 += part[(int64_t)(k + 1) * slab + idx];
+    s2 += part[(int64_t)(k + 2) * slab + idx];
+    s3 += part[(int64_t)(k + 3) * slab + idx];
+  }
+  for (; k < nslab; ++k) s0 += part[(int64_t)k * slab + idx];
+  const float v = (s0 + s1) + (s2 + s3);
+  if (i == C * 32) { if (colsum_s) colsum_s[0] += v; return; }
+  const int c = i >> 5, tp = i & 31;
+  if (tp < 27) dw[c * 27 + tp] += v;
+  else if (tp == 27 && colsum_m) colsum_m[c] += v;
+}
+
 bool c1_dims_ok(int N, int D, int H, int W, int C) {
   return N > 0 && D > 0 && H > 0 && W > 0 && C >= 8 && C <= 64 && (C & 7) == 0 && (int64_t)N * D * H * W < (1ll << 31);
 }
@@ -191,6 +328,42 @@ int mi_launch_c1_reduce(const void* x, int x_cs, const float* w, const float* ad
     attr_done[nk - 1] = true;
   }
   hipLaunchKernelGGL(k, dim3((unsigned)tiles), dim3(256), lds, st, a);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+// Weight gradient of the 1 -> C conv (flip = 0: m = dy, s = x; colsum_m = the bias gradient [C]) or of the C -> 1 conv (flip = 1:
+// m = x, s = dy; colsum_s = the bias gradient [1]).  dw: fp32 [C][27] torch layout (either conv), accumulated.  part: scratch of
+// mi_c1_wgrad_scratch_floats(C) floats.
+int mi_c1_wgrad_slabs() { return 512; }
+int64_t mi_c1_wgrad_scratch_floats(int C) { return (int64_t)mi_c1_wgrad_slabs() * (((C + 31) / 32) * 1024 + 32); }
+int mi_launch_c1_wgrad(const void* m, int m_cs, const void* s1, int s_cs, float* dw, float* colsum_m, float* colsum_s, float* part, int N, int D,
+                       int H, int W, int C, int flip, hipStream_t st) {
+  if (!c1_dims_ok(N, D, H, W, C) || !part) return MI_ERR_UNSUPPORTED;
+  const int64_t tiles = (int64_t)N * ((D + kTD - 1) / kTD) * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+  if (tiles >= (1ll << 31)) return MI_ERR_UNSUPPORTED;
+  C1WgArgs a{};
+  a.N = N; a.D = D; a.H = H; a.W = W; a.C = C;
+  a.m = (const bf16*)m; a.m_cs = m_cs; a.s = (const bf16*)s1; a.s_cs = s_cs; a.part = part; a.ntiles = (int)tiles; a.flip = flip;
+  const int ncb = (C + 31) / 32;
+  int grid = mi_c1_wgrad_slabs();
+  if (grid > tiles) grid = (int)tiles;
+  {
+    const int pitch = ncb * 64, mt = 64 * pitch, hsb = (3 * kHH * kHW * 2 + 15) / 16 * 16;
+    size_t lds = 4 * (size_t)(2 * mt + 2 * hsb);
+    const size_t need_red = sizeof(float) * (size_t)(4 * ncb * 1024 + 4);
+    if (lds < need_red) lds = need_red;
+    static bool attr_done[2] = {false, false};
+    auto kern = ncb == 1 ? k_c1_wgrad<1> : k_c1_wgrad<2>;
+    if (!attr_done[ncb - 1]) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      if (e != hipSuccess) return (int)e;
+      attr_done[ncb - 1] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
+  }
+  const int slab = ncb * 1024 + 32;
+  hipLaunchKernelGGL(k_c1_wgrad_reduce, dim3((C * 32 + 1 + 255) / 256), dim3(256), 0, st, part, grid, slab, C, dw, colsum_m, colsum_s);
   MI_CHECK_LAUNCH();
   return 0;
 }
