@@ -9,6 +9,8 @@
 //                  600-voxel LDS halo of s.  One HBM pass over m (the table-driven MFMA kernel padded the 1-channel side to 32: 199 us
 //                  per call at 128^3 for a 134 MB read).
 // W is the fp32 master weight in torch layout ([C][1][27] or [1][C][27]: index c * 27 + t either way) read through the scalar cache.
+#include <stdlib.h>
+
 #include "common.h"
 #include "conv_common.h"
 #include "medimgen_hip.h"
@@ -80,8 +82,114 @@ __global__ void __launch_bounds__(256) k_c1_expand(C1Args a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------- C -> 1 forward
+// ---------------------------------------------------------------------------------------------- 1 -> C on the MFMA
+// The same product with the 27 taps as the K axis: D[c][v] = W[c][t] B[t][v], B[t][v] = s[v + t] gathered from a wave-private LDS
+// halo (3 slices x 10 x 10) of the single-channel tensor; two k-steps of 16 taps (27 padded to 32) per block of 32 voxels.  The
+// weight rows are permuted like k_conv27's (MFMA row rho <-> channel 16 ((rho >> 2) & 1) + (rho & 3) + 4 (rho >> 3)) so that a
+// lane's 16 accumulator registers are 16 CONSECUTIVE channels of its voxel: the result is stored straight from the registers as
+// two 16-byte pieces per lane, no staging tile, no 864-FMA VALU loop.  One HBM write pass (the VALU kernel above: 86 us at 128^3
+// for a 134 MB write).
 constexpr int kTD = 4, kTH = 8, kTW = 8, kHD = kTD + 2, kHH = kTH + 2, kHW = kTW + 2, kHalo = kHD * kHH * kHW;  // 600 halo voxels
+template <int NCB, int FLIP>
+__global__ void __launch_bounds__(256) k_c1_expand_mfma(C1Args a, int ntiles) {
+  constexpr int HS = 3 * kHH * kHW;
+  __shared__ bf16 sh[4][2][HS + 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, v = lane & 31, h = lane >> 5;
+  const int tw = (a.W + kTW - 1) / kTW, th = (a.H + kTH - 1) / kTH, td = (a.D + kTD - 1) / kTD;
+  // A fragments: row rho = v (lane & 31) carries channel crow; k = tap ks * 16 + 8 h + j
+  const int crow = 16 * ((v >> 2) & 1) + (v & 3) + 4 * (v >> 3);
+  bf16x8 wf[NCB][2];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      F8 f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int tap = ks * 16 + 8 * h + j, c = cb * 32 + crow;
+        f.v[j] = (tap < 27 && c < a.C) ? a.w[c * 27 + (FLIP ? 26 - tap : tap)] : 0.f;
+      }
+      wf[cb][ks] = __builtin_bit_cast(bf16x8, pack8(f));
+    }
+  // halo offsets of this lane's 8 taps per k-step, relative to the voxel's own halo position
+  int toff[2][8];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int tap = ks * 16 + 8 * h + j, t2 = tap < 27 ? tap : 13;
+      toff[ks][j] = (t2 / 9) * (kHH * kHW) + ((t2 / 3) % 3) * kHW + t2 % 3;
+    }
+  bf16 sreg[5];
+  auto issue = [&](int tile) {
+    int r = tile;
+    const int tx = r % tw; r /= tw;
+    const int ty = r % th; r /= th;
+    const int tz = r % td, n = r / td;
+    const int z = tz * kTD + wave, y0 = ty * kTH, x0 = tx * kTW;
+    const bf16* sn = a.s + (int64_t)n * a.D * a.H * a.W * a.s_cs;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int hi = i * 64 + lane;
+      const int hx = hi % kHW, hy = (hi / kHW) % kHH, hz = hi / (kHW * kHH);
+      const int zz = z + hz - 1, yy = y0 + hy - 1, xx = x0 + hx - 1;
+      const bool in = hi < HS && (unsigned)zz < (unsigned)a.D && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+      sreg[i] = in ? sn[(((int64_t)zz * a.H + yy) * a.W + xx) * a.s_cs] : f2bf(0.f);
+    }
+  };
+  int tile = blockIdx.x, buf = 0;
+  if (tile < ntiles) issue(tile);
+  for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    bf16* hb = sh[wave][buf];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int hi = i * 64 + lane;
+      if (hi < HS) hb[hi] = sreg[i];
+    }
+    int r = tile;
+    const int tx = r % tw; r /= tw;
+    const int ty = r % th; r /= th;
+    const int tz = r % td, n = r / td;
+    const int z = tz * kTD + wave;
+    if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {  // 32 voxels: rows 4 blk .. 4 blk + 3 of this wave's d-slice
+      const int row = 4 * blk + (v >> 3), col = v & 7;
+      const int base = row * kHW + col;  // halo position of (slice 0, row, col); tap (1,1,1) is the voxel itself
+      f32x16 acc[NCB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int c = cb * 32 + 16 * h + e;
+          acc[cb][e] = (a.addvec && c < a.C) ? a.addvec[(int64_t)n * a.av_stride + c] : 0.f;
+        }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 bfr;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bfr[j] = (ks * 16 + 8 * h + j) < 27 ? hb[base + toff[ks][j]] : f2bf(0.f);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cb][ks], bfr, acc[cb], 0, 0, 0);
+      }
+      const int y = ty * kTH + row, x = tx * kTW + col;
+      if (z < a.D && y < a.H && x < a.W) {
+        bf16* out = a.y + ((((int64_t)n * a.D + z) * a.H + y) * a.W + x) * a.y_cs;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int c0 = cb * 32 + 16 * h;
+          F8 lo, hi;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { lo.v[e] = acc[cb][e]; hi.v[e] = acc[cb][8 + e]; }
+          if (c0 < a.C) *(u32x4*)(out + c0) = pack8(lo);
+          if (c0 + 8 < a.C) *(u32x4*)(out + c0 + 8) = pack8(hi);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- C -> 1 forward
 constexpr int kYP = 33;  // Y row pitch in floats (odd: the 27 shifted reads of a wave hit distinct banks)
 
 template <int NK>  // k-steps of 16 channels
@@ -302,6 +410,21 @@ int mi_launch_c1_expand(const void* s, int s_cs, const float* w, const float* ad
   C1Args a{};
   a.N = N; a.D = D; a.H = H; a.W = W; a.C = C;
   a.s = (const bf16*)s; a.s_cs = s_cs; a.w = w; a.addvec = addvec; a.av_stride = av_stride; a.y = (bf16*)y; a.y_cs = y_cs;
+  static const int use_mfma = [] { const char* e = getenv("MI_C1_EXPAND_MFMA"); return e ? atoi(e) : 1; }();
+  const int64_t tiles = (int64_t)N * ((D + kTD - 1) / kTD) * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+  if (use_mfma && tiles < (1ll << 31)) {
+    const int grid = (int)(tiles < 2048 ? tiles : 2048);  // persistent: 8 workgroups of 4 waves per CU
+    const int ncb = (C + 31) / 32;
+    if (ncb == 1) {
+      if (flip) hipLaunchKernelGGL((k_c1_expand_mfma<1, 1>), dim3(grid), dim3(256), 0, st, a, (int)tiles);
+      else hipLaunchKernelGGL((k_c1_expand_mfma<1, 0>), dim3(grid), dim3(256), 0, st, a, (int)tiles);
+    } else {
+      if (flip) hipLaunchKernelGGL((k_c1_expand_mfma<2, 1>), dim3(grid), dim3(256), 0, st, a, (int)tiles);
+      else hipLaunchKernelGGL((k_c1_expand_mfma<2, 0>), dim3(grid), dim3(256), 0, st, a, (int)tiles);
+    }
+    MI_CHECK_LAUNCH();
+    return 0;
+  }
   const int64_t total = (int64_t)N * D * H * W;
   dim3 grid((unsigned)((total + 255) / 256));
   if (flip) hipLaunchKernelGGL(k_c1_expand<1>, grid, dim3(256), 0, st, a);
