@@ -1,6 +1,6 @@
-"""The BASELINE.json configs at their FULL sizes.  The metric's own workload (C4, 128^3 x 1) and C2 (96^3) are
-compared with the CPU oracle directly (one oracle step at 128^3 takes ~20 s on the GPU box's 16 host cores); the larger latent
-nets through size-independent properties:
+"""The BASELINE.json configs at their FULL sizes.  The metric's own workload (C4, 128^3 x 1), C2 (96^3) and the C3a
+autoencoder (128^3) are compared with the CPU oracle directly (one oracle step at 128^3 takes ~20 s on the GPU box's 16 host
+cores); the larger latent nets through size-independent properties:
   * finite loss and finite gradients on every trainable parameter slot;
   * reproducibility: two runs of the same step on the same inputs agree to fp32 summation-order noise (rel-L2 <= 1e-5 on the
     gradient arena; the bias / GroupNorm-parameter / 1x1-weight-gradient reductions and the scalar loss finish with fp32
@@ -148,9 +148,22 @@ def test_c3a_full_size():
         mu1, sigma1 = net.encode(x1)
         rec, rec1 = net.decode(mu), net.decode(mu1)
     assert mu.shape == (2, 8, 32, 32, 32) and rec.shape == x.shape
-    # batch 2 and batch 1 run different register-blocking variants (the plan goes by workgroup count): two bf16 evaluations of the same
-    # function, each within ~1e-2 of fp32 (tests/test_aekl_gpu.py: z_mu 1.2e-2, recon 1.4e-2 against the reference) -> <= 3e-2 apart
-    rel = lambda a, b: float((a - b).norm() / b.norm())
-    assert rel(mu[:1], mu1) <= 3e-2 and rel(sigma[:1], sigma1) <= 3e-2 and rel(rec[:1], rec1) <= 3e-2
+    # batch 2 and batch 1 run different register-blocking variants (the plan goes by workgroup count), so they are two bf16 evaluations
+    # of the same function: each must sit within the bf16 budget of the fp32 oracle AT FULL SIZE (encode, then decode of the oracle's
+    # own posterior mean so that the decoder error is not the encoder's carried along)
+    from oracle import nets
+    torch.set_num_threads(16)
+    ref = nets.AutoencoderKL(**cases.AEKL_CASES["aekl_c3a"]["kwargs"])
+    ref.load_state_dict({k: v.detach().cpu() for k, v in net.state_dict().items()})
+    with torch.no_grad():
+        mu_r, sigma_r = ref.encode(x1.cpu())
+        rec_r = ref.decode(mu_r)
+        rec_h2, rec_h1 = net.decode(mu_r.to(dev).repeat(2, 1, 1, 1, 1)), net.decode(mu_r.to(dev))
+    rel = lambda a, b: float((a.cpu() - b).norm() / b.norm())
+    errs = {"mu b2": rel(mu[:1], mu_r), "mu b1": rel(mu1, mu_r), "sigma b2": rel(sigma[:1], sigma_r), "sigma b1": rel(sigma1, sigma_r),
+            "rec b2": rel(rec_h2[:1], rec_r), "rec b1": rel(rec_h1, rec_r)}
+    print("\n[C3a 128^3 vs fp32 oracle, full size] " + ", ".join(f"{k} {v:.3e}" for k, v in errs.items()))
+    assert max(errs.values()) <= 3e-2, errs
+    assert rel(rec[:1], rec1.cpu()) <= 6e-2  # end to end (encoder differences amplified by the decoder), batch 2 against batch 1
     assert torch.equal(mu[0], mu[1]) and torch.equal(rec[0], rec[1])  # identical samples of one batch: bit-identical
     print(f"\n[C3a 128^3 b2] loss {l1:.5f}, |grad| {float(g1.norm()):.4e}, finite, batch-consistent; run-to-run gradient rel-L2 {rep:.1e}")
