@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmedimgen_hip.so")
+LIB_PATH = os.environ.get("MI_LIB_PATH") or os.path.join(_HERE, "libmedimgen_hip.so")  # MI_LIB_PATH: ablation builds (csrc/Makefile `diag`)
 
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 

@@ -805,12 +805,15 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 template <int MAXP>
 struct DmaPieces {
-  int pk[MAXP];  // per piece of this wave: packed coordinates of the lane's voxel ((a << 20) | (b << 10) | c) or -1
+  int pk[MAXP];        // per piece of this wave: packed coordinates of the lane's voxel ((a << 20) | (b << 10) | c) or -1
+  unsigned off[MAXP];  // ... and the byte offset of the lane's 16 bytes from the image's origin voxel (0 for lanes past the image)
 };
+// (A loader wave shares its SIMD's vector issue with two compute waves' MFMAs: per-piece address arithmetic is what it cannot
+// afford.  Tiles whose image lies inside the tensor use off[] + a scalar base and no per-lane checks; see k_conv27.)
 
 // x halo image: piece i (1 KiB) -> halo voxels 16 i .. 16 i + 15, lane -> voxel 16 i + (lane >> 2), 16-byte part lane & 3
 template <int MAXP>
-__device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane) {
+__device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane, int Hi, int Wi, int cs) {
   const int hvox = g.HD * g.HH * g.HW;
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
@@ -818,6 +821,7 @@ __device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, in
     const int v = i * 16 + (lane >> 2);
     const int hd = v / (g.HH * g.HW), rem = v - hd * (g.HH * g.HW), hh = rem / g.HW, hw = rem - hh * g.HW;
     d.pk[k] = (i < npieces && v < hvox) ? ((hd << 20) | (hh << 10) | hw) : -1;
+    d.off[k] = (i < npieces && v < hvox) ? (unsigned)(((hd * Hi + hh) * Wi + hw) * cs + (lane & 3) * 8) * 2u : 0u;
   }
 }
 template <int MAXP>
@@ -826,20 +830,32 @@ __device__ __forceinline__ void dma_issue_x(const DmaPieces<MAXP>& d, const Conv
   const Geom& g = a.g;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
   const int c = src_c0 + (lane & 3) * 8;
+  const int od = d0 - g.hd, oh = h0 - g.hh, ow = w0 - g.hw;
+  const unsigned base = (unsigned)((((n * a.Di + od) * a.Hi + oh) * a.Wi + ow) * a.x_cs + src_c0) * 2u;  // scalar (mod 2^32)
+  const bool interior = valid & (od >= 0) & (od + g.HD <= a.Di) & (oh >= 0) & (oh + g.HH <= a.Hi) & (ow >= 0) & (ow + g.HW <= a.Wi) & (src_c0 + 32 <= a.Cin);
+  if (interior) {
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int i = first + stride * k;
+      if (i >= npieces) break;  // wave-uniform
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(dst + i * 1024), 16, d.off[k], (int)base, 0, 0);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
     const int i = first + stride * k;
     if (i >= npieces) break;  // wave-uniform
     const int pk = d.pk[k];
-    const int gd = d0 - g.hd + (pk >> 20), gh = h0 - g.hh + ((pk >> 10) & 1023), gw = w0 - g.hw + (pk & 1023);
+    const int gd = od + (pk >> 20), gh = oh + ((pk >> 10) & 1023), gw = ow + (pk & 1023);
     const bool ok = valid & (pk >= 0) & ((unsigned)gd < (unsigned)a.Di) & ((unsigned)gh < (unsigned)a.Hi) & ((unsigned)gw < (unsigned)a.Wi) & (c + 8 <= a.Cin);
-    const unsigned off = ok ? (unsigned)((((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.x_cs + c) * 2u : 0xfffffff0u;
+    const unsigned off = ok ? d.off[k] + base : 0xfffffff0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(dst + i * 1024), 16, off, 0, 0, 0);
   }
 }
 // dY tile image: [TD][TH][TW] voxels x 64 B, channels y*32 ..
 template <int MAXP>
-__device__ __forceinline__ void dma_init_y(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane) {
+__device__ __forceinline__ void dma_init_y(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane, int Ho, int Wo, int cs) {
   const int nvox = g.TD * g.TH * g.TW;
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
@@ -847,6 +863,7 @@ __device__ __forceinline__ void dma_init_y(DmaPieces<MAXP>& d, const Geom& g, in
     const int v = i * 16 + (lane >> 2);
     const int vd = v / (g.TH * g.TW), rem = v - vd * (g.TH * g.TW), vh = rem / g.TW, vw = rem - vh * g.TW;
     d.pk[k] = (i < npieces && v < nvox) ? ((vd << 20) | (vh << 10) | vw) : -1;
+    d.off[k] = (i < npieces && v < nvox) ? (unsigned)(((vd * Ho + vh) * Wo + vw) * cs + (lane & 3) * 8) * 2u : 0u;
   }
 }
 template <int MAXP>
@@ -855,6 +872,18 @@ __device__ __forceinline__ void dma_issue_y(const DmaPieces<MAXP>& d, const Wgra
   const ConvArgs& a = w.c;
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(w.dy, w.dy_bytes);
   const int co = y * 32 + (lane & 3) * 8;
+  const Geom& g = a.g;
+  const unsigned base = (unsigned)((((n * a.Do + d0) * a.Ho + h0) * a.Wo + w0) * w.dy_cs + y * 32) * 2u;  // scalar (mod 2^32)
+  const bool interior = valid & (d0 + g.TD <= a.Do) & (h0 + g.TH <= a.Ho) & (w0 + g.TW <= a.Wo) & (y * 32 + 32 <= a.Cout);
+  if (interior) {
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const int i = first + stride * k;
+      if (i >= npieces) break;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void_t*)(dst + i * 1024), 16, d.off[k], (int)base, 0, 0);
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
     const int i = first + stride * k;
@@ -862,7 +891,7 @@ __device__ __forceinline__ void dma_issue_y(const DmaPieces<MAXP>& d, const Wgra
     const int pk = d.pk[k];
     const int od = d0 + (pk >> 20), oh = h0 + ((pk >> 10) & 1023), ow = w0 + (pk & 1023);
     const bool ok = valid & (pk >= 0) & (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co + 8 <= a.Cout);
-    const unsigned off = ok ? (unsigned)((((n * a.Do + od) * a.Ho + oh) * a.Wo + ow) * w.dy_cs + co) * 2u : 0xfffffff0u;
+    const unsigned off = ok ? d.off[k] + base : 0xfffffff0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void_t*)(dst + i * 1024), 16, off, 0, 0, 0);
   }
 }
@@ -911,16 +940,21 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     const int first = wave - 8;
     DmaPieces<MAXPX> dx;
     DmaPieces<MAXPY> dyp;
-    dma_init_x<MAXPX>(dx, g, first, 4, px, lane);
-    dma_init_y<MAXPY>(dyp, g, first, 4, py, lane);
+    dma_init_x<MAXPX>(dx, g, first, 4, px, lane, a.Hi, a.Wi, a.x_cs);
+    dma_init_y<MAXPY>(dyp, g, first, 4, py, lane, a.Ho, a.Wo, w.dy_cs);
     // ring of NB image pairs (w.nbuf: 2, or 4 for the 1x1 k-split pairs whose tiles are all loads and hardly any MFMA): tile i
     // lives in slot i % NB and is requested NB-1 tiles ahead.  Requests beyond the last tile are still issued (all lanes out of
     // range: zeros into a free slot) so that the counted vmcnt below stays exact.
     const int NB = w.nbuf;
+    TileWalk walk;  // requests go t0, t0 + tstep, ... in order: stepped, not divided (conv_common.h)
+    walk_init(walk, g, t0, tstep);
+    bool first_request = true;
     auto request = [&](int t, int slot) {
       int n, d0, h0, w0;
       const bool valid = t < tend;
-      tile_origin(g, valid ? t : t0, n, d0, h0, w0);
+      if (!first_request) walk_step(walk, g);
+      first_request = false;
+      walk_origin(walk, g, n, d0, h0, w0);  // (past the end: every lane is masked, the origin does not matter)
       dma_issue_x<MAXPX>(dx, a, lds + slot * XB, first, 4, px, lane, n, d0, h0, w0, src_c0, valid);
       dma_issue_y<MAXPY>(dyp, w, lds + NB * XB + slot * YB, first, 4, py, lane, y, n, d0, h0, w0, valid);
     };
@@ -968,7 +1002,9 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
   const int dyrow = g.TW * g.vox, dyslice = g.TH * dyrow;
   int tile = t0, n, d0, h0, w0, buf = 0;
   const int NB = w.nbuf;
-  tile_origin(g, tile, n, d0, h0, w0);
+  TileWalk walk;
+  walk_init(walk, g, t0, tstep);
+  walk_origin(walk, g, n, d0, h0, w0);
   const bool do_colsum = w.colsum != nullptr && (pair % a.nchunks) == 0;
   const bool cs_wave = do_colsum && (ksplit || wave == 7);
   f32x16& cs = acc[3];
@@ -1034,7 +1070,8 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     if (next >= tend) break;
     tile = next;
     buf = buf + 1 == NB ? 0 : buf + 1;
-    tile_origin(g, tile, n, d0, h0, w0);
+    walk_step(walk, g);
+    walk_origin(walk, g, n, d0, h0, w0);
   }
   if (cs_wave) cs_flush(cs_n);
 
@@ -1067,6 +1104,11 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     }
   }
 }
+
+// Both instantiations spelled out: with only the implicit ones (the ternary / if-else in the launcher) hipcc 7.2 emitted the host stub
+// of just one of them (the other stayed an undefined symbol of the shared object; no diagnostic).
+template __global__ void k_conv_wgrad2<true>(WgradArgs);
+template __global__ void k_conv_wgrad2<false>(WgradArgs);
 
 // ------------------------------------------------------------------------------------------------ weight pack / unpack
 // frag_items[f] = {src_tap, co0, ci0, flags}: fragment f holds A[row = co0 + r][k = ci0 + 8h + j] (kernel channel indices);

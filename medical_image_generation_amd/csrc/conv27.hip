@@ -48,7 +48,26 @@ template <> struct Cfg<2> { static constexpr int GT = 3; };  // 9 groups of 3 ta
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-__device__ unsigned long long g_c27_clk[4];  // diagnostic (MI_C27_DBG & 64): shader-clock and 100 MHz real-time ticks of workgroup 0's main loop
+// Ablation builds (tools/diag/c27_ablate.sh; never the shipped library): -DMI_C27_DIAG_A / _B drop the weight / activation fragment
+// reads of the compute waves, _HALO / _W the helper waves' LDS-DMA, _NOBAR every s_barrier.  Results are garbage; every wave still
+// runs the same loop to the same exit, and no address leaves its buffer.
+#ifdef MI_C27_DIAG_NOBAR
+#define C27_BARRIER() do {} while (0)
+#else
+#define C27_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+// -DMI_C27_DIAG_BAR: shader cycles spent inside the barriers, by position in the image (top 0 / top 1 / tops 2..NG-2 / top NG-1)
+#ifdef MI_C27_DIAG_BAR
+#define C27_BARRIER_T(acc) do { const unsigned long long t0__ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_barrier(); (acc) += __builtin_amdgcn_s_memtime() - t0__; } while (0)
+#define C27_T0() const unsigned long long tt0__ = __builtin_amdgcn_s_memtime()
+#define C27_T1(acc) (acc) += __builtin_amdgcn_s_memtime() - tt0__
+#else
+#define C27_BARRIER_T(acc) C27_BARRIER()
+#define C27_T0() do {} while (0)
+#define C27_T1(acc) do {} while (0)
+#endif
+
+__device__ unsigned long long g_c27_clk[16];  // diagnostic (MI_C27_DBG & 64): shader-clock and 100 MHz real-time ticks of workgroup 0's main loop
 
 template <int NCB>
 struct K {
@@ -61,6 +80,15 @@ struct K {
   static constexpr int AV_WAVE = NCB * 2 * 64;  // per compute wave: bias (+ time embedding) of its accumulator channels [cb][h][16] fp32
   static constexpr int LDS_TOTAL = AV0 + 4 * AV_WAVE;
   static constexpr int PPT = (PV + NG - 2) / (NG - 1);  // store-epilogue pieces (of PV per helper wave and tile) processed per tap group
+  // The next image's halo pieces are dealt over the first NH tops: an LDS-DMA instruction issued beside the compute waves' fragment
+  // reads costs its wave 110-190 cycles, and a top that carries all 10 of them next to its weight pieces takes twice a tap group's
+  // time (measured, 64->64 @128^3: the compute waves spent 12 % of the kernel inside the top-1 barrier).  Not at top NG-2: what is
+  // issued there is retired only together with that top's stores.
+#ifndef MI_C27_NH
+#define MI_C27_NH 1
+#endif
+  static constexpr int NH = NG - 2 < MI_C27_NH ? (NG - 2 < 1 ? 1 : NG - 2) : MI_C27_NH;
+  static constexpr int hbeg(int j) { return j >= NH ? 10 : (j * 10) / NH; }  // first piece of top j (10 = HPW)
 };
 
 template <int N>
@@ -71,6 +99,22 @@ __device__ __forceinline__ void wait_vm() {
 template <int OFF>
 __device__ __forceinline__ void lds_read16(u32x4& dst, unsigned addr) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16_a(u32x4& dst, unsigned addr) {
+#ifdef MI_C27_DIAG_A
+  asm volatile("" : "+v"(dst) : "v"(addr));
+#else
+  lds_read16<OFF>(dst, addr);
+#endif
+}
+template <int OFF>
+__device__ __forceinline__ void lds_read16_b(u32x4& dst, unsigned addr) {
+#ifdef MI_C27_DIAG_B
+  asm volatile("" : "+v"(dst) : "v"(addr));
+#else
+  lds_read16<OFF>(dst, addr);
+#endif
 }
 
 template <int NCB>
@@ -101,14 +145,14 @@ __device__ __forceinline__ void issue_one(Frags<NCB>& f, const unsigned (&bb)[2]
   constexpr int HALF = 2 + NCB;  // reads per k-step
   constexpr int ks = Q / HALF, q = Q % HALF;
   if constexpr (NCB == 2) {
-    if constexpr (q == 0) lds_read16<BOFF>(f.b[ks][0], bb[0][TH][ks]);
-    else if constexpr (q == 1) lds_read16<((t * 2 + ks) * 2 + 0) * 1024>(f.a[ks][0], ab);
-    else if constexpr (q == 2) lds_read16<((t * 2 + ks) * 2 + 1) * 1024>(f.a[ks][1], ab);
-    else lds_read16<BOFF>(f.b[ks][1], bb[1][TH][ks]);
+    if constexpr (q == 0) lds_read16_b<BOFF>(f.b[ks][0], bb[0][TH][ks]);
+    else if constexpr (q == 1) lds_read16_a<((t * 2 + ks) * 2 + 0) * 1024>(f.a[ks][0], ab);
+    else if constexpr (q == 2) lds_read16_a<((t * 2 + ks) * 2 + 1) * 1024>(f.a[ks][1], ab);
+    else lds_read16_b<BOFF>(f.b[ks][1], bb[1][TH][ks]);
   } else {
-    if constexpr (q == 0) lds_read16<BOFF>(f.b[ks][0], bb[0][TH][ks]);
-    else if constexpr (q == 1) lds_read16<(t * 2 + ks) * 1024>(f.a[ks][0], ab);
-    else lds_read16<BOFF>(f.b[ks][1], bb[1][TH][ks]);
+    if constexpr (q == 0) lds_read16_b<BOFF>(f.b[ks][0], bb[0][TH][ks]);
+    else if constexpr (q == 1) lds_read16_a<(t * 2 + ks) * 1024>(f.a[ks][0], ab);
+    else lds_read16_b<BOFF>(f.b[ks][1], bb[1][TH][ks]);
   }
 }
 template <int T, int NCB, int FLIP>
@@ -173,10 +217,11 @@ __device__ __forceinline__ void tap_body(f32x16 (&acc)[2][NCB], Frags<NCB>& cur,
 struct Seq {
   int tile, ch, n, d0, h0, w0;          // current image
   int ntile, nch, nn, nd0, nh0, nw0;    // next image (ntile < 0: none)
+  TileWalk walk;                        // digits of the furthest tile looked at (the next one once seq_next has stepped)
 };
 __device__ __forceinline__ void seq_next(Seq& q, const ConvArgs& a, int tile_step, int tile_last) {
   if (q.ch + 1 < a.nchunks) { q.ntile = q.tile; q.nch = q.ch + 1; q.nn = q.n; q.nd0 = q.d0; q.nh0 = q.h0; q.nw0 = q.w0; }
-  else if (q.tile + tile_step < tile_last) { q.ntile = q.tile + tile_step; q.nch = 0; tile_origin(a.g, q.ntile, q.nn, q.nd0, q.nh0, q.nw0); }
+  else if (q.tile + tile_step < tile_last) { q.ntile = q.tile + tile_step; q.nch = 0; walk_step(q.walk, a.g); walk_origin(q.walk, a.g, q.nn, q.nd0, q.nh0, q.nw0); }
   else { q.ntile = -1; q.nch = 0; q.nn = q.nd0 = q.nh0 = q.nw0 = 0; }
 }
 __device__ __forceinline__ void seq_advance(Seq& q) {
@@ -193,12 +238,18 @@ struct CState {
   int av_n;                    // image index the LDS bias table of this wave was loaded for
   int cur;                     // halo buffer of the current image
   int slot;                    // ring slot of the previous group
+  int resident;                // single chunk whose weight groups all fit the ring: loaded once, inner barriers skipped
+  unsigned long long bw[4];    // MI_C27_DIAG_BAR
 };
 
 template <int J, int NCB>
 __device__ __forceinline__ void compute_top(CState<NCB>& s, int lane) {
   using KK = K<NCB>;
-  __builtin_amdgcn_s_barrier();  // group J+1's weights (and, at the last group, the next image's halo) are in LDS for every wave
+  // group J+1's weights (and, at the last group, the next image's halo) are in LDS for every wave.  With the whole chunk resident in
+  // the ring the inner barriers publish nothing: without them the helper waves have the whole image, not one tap group, for the halo
+  // DMA and the store epilogue (measured, 32->32 @128^3: the compute waves spent 16 % of the kernel inside the top-1 barrier waiting
+  // for helpers still issuing the halo)
+  if (J == 0 || J == KK::NG - 1 || !s.resident) C27_BARRIER_T(s.bw[J < 2 ? J : (J == KK::NG - 1 ? 3 : 2)]);
   const int sj = s.slot + 1 == RD ? 0 : s.slot + 1;  // slot of group J
   const int sj1 = sj + 1 == RD ? 0 : sj + 1;         // slot of group J+1
   s.abase = KK::RING0 + sj * KK::GROUP_BYTES + lane * 16;
@@ -291,15 +342,18 @@ __device__ __forceinline__ void compute_role(const ConvArgs& a, char* lds, int y
   }
   Seq q;
   q.tile = tile0; q.ch = 0;
-  tile_origin(a.g, tile0, q.n, q.d0, q.h0, q.w0);
+  walk_init(q.walk, a.g, tile0, tile_step);
+  walk_origin(q.walk, a.g, q.n, q.d0, q.h0, q.w0);
   load_av<NCB>(s, a, lds, y, wave, lane, q.n);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   init_acc<NCB>(s, lds, wave, lane);
   s.cur = 0;
+  s.bw[0] = s.bw[1] = s.bw[2] = s.bw[3] = 0;
+  s.resident = a.nchunks == 1 && K<NCB>::NG <= RD;
   s.slot = RD - 1;  // "slot of group -1": compute_top<0> steps to slot 0
   s.abase = s.abase_next = K<NCB>::RING0 + lane * 16;
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing of this wave's is in flight across the barriers
-  __builtin_amdgcn_s_barrier();  // prologue: first halo image and weight groups 0, 1 are in LDS
+  C27_BARRIER();  // prologue: first halo image and weight groups 0, 1 are in LDS
   issue_frags<0, NCB, FLIP>(s.fr[0], s.bcur, s.abase);
   wait_frags<NCB>(s.fr[0]);
   unsigned long long t0 = 0, r0 = 0;
@@ -327,8 +381,9 @@ __device__ __forceinline__ void compute_role(const ConvArgs& a, char* lds, int y
   if ((a.dbg & 64) && blockIdx.x == 0 && blockIdx.y == 0 && wave == 0 && lane == 0) {
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     g_c27_clk[0] = t1 - t0; g_c27_clk[1] = r1 - r0;
+    for (int i = 0; i < 4; ++i) g_c27_clk[4 + i] = s.bw[i];
   }
-  __builtin_amdgcn_s_barrier();  // final: the last tile's staging is complete
+  C27_BARRIER();  // final: the last tile's staging is complete
 }
 
 // ------------------------------------------------------------------------------------------------ helper waves (4-7)
@@ -353,6 +408,9 @@ __device__ __forceinline__ void issue_A(const ConvArgs& a, char* lds, int y, int
   // fragments are packed [cout group][chunk][tap][ks][cb] and every chunk of a k3 s1 conv has all 27 taps: no table lookup
   // (a load inside the loop would be a VECTOR load -- the kernel stores to global memory -- and drain the DMA queue)
   const int wfrag = (y * a.nchunks + ch) * (27 * 2 * NCB) + j * KK::FRAGS;
+#ifdef MI_C27_DIAG_W
+  return;
+#endif
 #pragma unroll
   for (int i = 0; i < (KK::FRAGS + 3) / 4; ++i) {
     const int f = hl + 4 * i;
@@ -362,17 +420,34 @@ __device__ __forceinline__ void issue_A(const ConvArgs& a, char* lds, int y, int
   }
 }
 
-__device__ __forceinline__ void issue_halo(const ConvArgs& a, char* lds, const int (&hp)[HPW], int hl, int buf, int valid, int n, int d0, int h0,
-                                           int w0, int src_c0) {
+template <int K0, int K1>  // pieces K0 .. K1-1 of this wave's HPW
+__device__ __forceinline__ void issue_halo(const ConvArgs& a, char* lds, const int (&hp)[HPW], const unsigned (&hoff)[HPW], int hl, int buf, int valid,
+                                           int n, int d0, int h0, int w0, int src_c0) {
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+#ifdef MI_C27_DIAG_HALO
+  return;
+#endif
+  // byte offset of the halo origin voxel (d0-1, h0-1, w0-1), channel src_c0: wave-uniform, lives in an SGPR (mod 2^32; tensors < 4 GiB)
+  const unsigned base = (unsigned)((((n * a.Di + d0 - 1) * a.Hi + (h0 - 1)) * a.Wi + (w0 - 1)) * a.x_cs + src_c0) * 2u;
+  // A helper wave shares its SIMD's vector issue with a compute wave that is issuing MFMAs: every VALU instruction here is paid for by
+  // the whole workgroup at the next barrier (measured: with ~25 address instructions per piece the compute waves spent 16-20 % of
+  // the kernel waiting for the helpers).  A tile whose halo lies inside the tensor needs none: the per-lane part of the address is a
+  // kernel-lifetime constant (hoff) and the tile's part goes into the instruction's scalar offset.
+  const bool interior = (valid != 0) & (d0 >= 1) & (d0 + 5 <= a.Di) & (h0 >= 1) & (h0 + 9 <= a.Hi) & (w0 >= 1) & (w0 + 9 <= a.Wi) & (src_c0 + 32 <= a.Cin);
+  if (interior) {
 #pragma unroll
-  for (int k = 0; k < HPW; ++k) {
+    for (int k = K0; k < K1; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(lds + buf * HALO_BYTES + (hl + 4 * k) * 1024), 16, hoff[k], (int)base, 0, 0);
+    return;
+  }
+#pragma unroll
+  for (int k = K0; k < K1; ++k) {
     const int pk = hp[k];
     const int gd = d0 - 1 + ((pk >> 16) & 255), gh = h0 - 1 + ((pk >> 8) & 255), gw = w0 - 1 + (pk & 255);
     const int c = src_c0 + ((pk >> 24) & 3) * 8;
     const bool ok = (valid != 0) & (pk >= 0) & ((unsigned)gd < (unsigned)a.Di) & ((unsigned)gh < (unsigned)a.Hi) & ((unsigned)gw < (unsigned)a.Wi) &
                     (c + 8 <= a.Cin);  // (bitwise: one select, no branches)
-    const unsigned off = ok ? (unsigned)((((n * a.Di + gd) * a.Hi + gh) * a.Wi + gw) * a.x_cs + c) * 2u : 0xfffffff0u;  // out of range -> zeros
+    const unsigned off = ok ? hoff[k] + base : 0xfffffff0u;  // out of range -> zeros
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(lds + buf * HALO_BYTES + (hl + 4 * k) * 1024), 16, off, 0, 0, 0);
   }
 }
@@ -383,6 +458,10 @@ template <int NCB>
 struct Epi {
   int n, d0, h0, w0;        // the tile being stored
   int active;               // a tile is pending
+  int full;                 // ... and lies inside the output with whole channel octets: no per-lane masks, addresses = lane constant + scalar
+  unsigned ybase, rbase;    // byte offsets of the tile's origin voxel (channel y*NCB*32) in y / in the residual
+  unsigned ylane, rlane, slane;  // this lane's constant part: voxel (lane / PV), slot (lane % PV) of a piece in y / residual / the staging tile
+  unsigned yps, rps;        // bytes from one piece to the next (8 / PV rows of the tile)
   u32x4 res[K<NCB>::PV];    // residual pieces, loaded one tap group ahead of their use
   float sa[8], sq[8];       // a.stats: running sum / sum of squares of this lane's channel octet over the tiles of image sn
   int sn;
@@ -433,17 +512,21 @@ __device__ __forceinline__ void stats_begin_tile(Epi<NCB>& e, const ConvArgs& a,
     e.sn = e.n;
   }
 }
+// Per-lane border masks of piece p (tiles that stick out of the output only): false -> the lane's access is dropped
 template <int NCB>
-__device__ __forceinline__ void epi_geometry(const Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane, int p, int& v, int& sidx, bool& inside,
-                                             unsigned& vox) {
+__device__ __forceinline__ bool epi_inside(const Epi<NCB>& e, const ConvArgs& a, int y, int hl, int lane, int p) {
   using KK = K<NCB>;
-  const int q = p * 64 + lane;
-  v = q / KK::PV;
-  sidx = q % KK::PV;
+  const int q = p * 64 + lane, v = q / KK::PV, sidx = q % KK::PV;
   const int od = e.d0 + hl, oh = e.h0 + (v >> 3), ow = e.w0 + (v & 7);
-  const int co = y * NCB * 32 + sidx * 8;
-  inside = (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co + 8 <= a.Cout);
-  vox = (unsigned)(((e.n * a.Do + od) * a.Ho + oh) * a.Wo + ow);
+  return (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (y * NCB * 32 + sidx * 8 + 8 <= a.Cout);
+}
+template <int NCB>
+__device__ __forceinline__ void epi_begin_tile(Epi<NCB>& e, const ConvArgs& a, int y, int n, int d0, int h0, int w0) {
+  e.active = 1; e.n = n; e.d0 = d0; e.h0 = h0; e.w0 = w0;
+  e.full = (d0 + 4 <= a.Do) & (h0 + 8 <= a.Ho) & (w0 + 8 <= a.Wo) & ((y + 1) * NCB * 32 <= a.Cout);
+  const unsigned vox = (unsigned)(((n * a.Do + d0) * a.Ho + h0) * a.Wo + w0);
+  e.ybase = (vox * (unsigned)a.y_cs + (unsigned)(y * NCB * 32)) * 2u;
+  e.rbase = (vox * (unsigned)a.res_cs + (unsigned)(y * NCB * 32)) * 2u;
 }
 // The residual pieces are ordinary compiler-tracked buffer loads issued one tap group before their use, and only when there is a
 // residual; the compiler places the vmcnt waits itself (conservatively: the helper wave waits for them almost at once, about a
@@ -459,12 +542,17 @@ __device__ __forceinline__ void epi_issue_res(Epi<NCB>& e, const ConvArgs& a, in
   const __amdgpu_buffer_rsrc_t rres = make_rsrc(a.res, a.res ? a.res_bytes : 0u);
 #pragma unroll
   for (int p = 0; p < KK::PV; ++p) {
-    int v, sidx; bool inside; unsigned vox;
-    epi_geometry<NCB>(e, a, y, hl, lane, p, v, sidx, inside, vox);
-    const unsigned off = (inside && enable) ? (vox * (unsigned)a.res_cs + (unsigned)(y * NCB * 32 + sidx * 8)) * 2u : 0xfffffff0u;
-    e.res[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0));
+    const unsigned so = e.rbase + (unsigned)p * e.rps;  // scalar
+    if (e.full) {
+      e.res[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)e.rlane, (int)so, 0));
+    } else {
+      const unsigned off = epi_inside<NCB>(e, a, y, hl, lane, p) ? e.rlane + so : 0xfffffff0u;
+      e.res[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, (int)off, 0, 0));
+    }
   }
 }
+// The helper waves share their SIMDs' vector issue with the compute waves' MFMAs, so VALU instructions here are the scarce thing:
+// an inside tile (e.full) costs no address arithmetic at all (lane constants + a scalar offset) and no statistics masks.
 template <int P0, int CNT, int NCB, bool ST>
 __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char* lds, int y, int hl, int lane, bool has_res) {
   using KK = K<NCB>;
@@ -472,31 +560,39 @@ __device__ __forceinline__ void epi_process(Epi<NCB>& e, const ConvArgs& a, char
 #pragma unroll
   for (int p = P0; p < P0 + CNT; ++p) {
     if (p >= KK::PV) break;
-    int v, sidx; bool inside; unsigned vox;
-    epi_geometry<NCB>(e, a, y, hl, lane, p, v, sidx, inside, vox);
-    const char* stg = lds + KK::STG0 + hl * KK::STG_WAVE;
-    u32x4 raw = *(const u32x4*)(stg + v * KK::VOXP + ((sidx ^ (v & (KK::PV - 1))) * 16));
-    const int co = y * NCB * 32 + sidx * 8;
+    u32x4 raw = *(const u32x4*)(lds + KK::STG0 + hl * KK::STG_WAVE + p * 1024 + e.slane);
     if (has_res) {
       F8 f = unpack8(raw), rr = unpack8(e.res[p]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) f.v[j] += rr.v[j];
       raw = pack8(f);
     }
-    if (ST && a.stats) {  // statistics of the ROUNDED values: what the consumer's GroupNorm will read
-      const F8 f = unpack8(raw);
-      const float mk = inside ? 1.f : 0.f;
+    const unsigned so = e.ybase + (unsigned)p * e.yps;  // scalar
+    // (stores are always issued -- masked lanes get an out-of-range offset: the store count is part of the vmcnt bookkeeping.  The
+    // host only sends whole channel octets with an 8-aligned pitch here; ragged outputs stay on the table-driven kernel.)
+    if (e.full) {
+      if (ST && a.stats) {  // statistics of the ROUNDED values: what the consumer's GroupNorm will read
+        const F8 f = unpack8(raw);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float t = mk * f.v[j];
-        e.sa[j] += t;
-        e.sq[j] = fmaf(t, f.v[j], e.sq[j]);
+        for (int j = 0; j < 8; ++j) {
+          e.sa[j] += f.v[j];
+          e.sq[j] = fmaf(f.v[j], f.v[j], e.sq[j]);
+        }
       }
-    }
-    {  // always issued (masked lanes get an out-of-range offset): the store count is part of the vmcnt bookkeeping.  The host only
-       // sends whole channel octets with an 8-aligned pitch here (ragged outputs stay on the table-driven kernel): an element-wise
-       // store path in every piece of every slot is code this kernel pays for even when it never runs (see stats_flush).
-      const unsigned off = inside ? (vox * (unsigned)a.y_cs + (unsigned)co) * 2u : 0xfffffff0u;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, raw), ry, (int)e.ylane, (int)so, 0);
+    } else {
+      const bool inside = epi_inside<NCB>(e, a, y, hl, lane, p);
+      if (ST && a.stats) {
+        const F8 f = unpack8(raw);
+        const float mk = inside ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = mk * f.v[j];
+          e.sa[j] += t;
+          e.sq[j] = fmaf(t, f.v[j], e.sq[j]);
+        }
+      }
+      const unsigned off = inside ? e.ylane + so : 0xfffffff0u;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, raw), ry, (int)off, 0, 0);
     }
   }
@@ -511,16 +607,53 @@ __device__ __forceinline__ void epi_slot(Epi<NCB>& e, const ConvArgs& a, char* l
   }
 }
 
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the immediates the helper's tops need)
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+  switch (n) {
+    case 0: wait_vm<0>(); break;
+    case 1: wait_vm<1>(); break;
+    case 2: wait_vm<2>(); break;
+    case 3: wait_vm<3>(); break;
+    case 4: wait_vm<4>(); break;
+    case 5: wait_vm<5>(); break;
+    case 6: wait_vm<6>(); break;
+    case 7: wait_vm<7>(); break;
+    case 8: wait_vm<8>(); break;
+    case 9: wait_vm<9>(); break;
+    case 10: wait_vm<10>(); break;
+    case 11: wait_vm<11>(); break;
+    case 12: wait_vm<12>(); break;
+    default: wait_vm<0>(); break;
+  }
+}
+// halo pieces of top j (J0 <= j) of the NEXT image
+template <int J0, int NCB>
+__device__ __forceinline__ void halo_part(const ConvArgs& a, char* lds, const int (&hp)[HPW], const unsigned (&hoff)[HPW], int hl, int buf, const Seq& q, int j) {
+  using KK = K<NCB>;
+  if constexpr (J0 < KK::NH) {
+    if (j == J0) {
+#ifdef MI_C27_DIAG_HOT  // every halo image of this workgroup = the origin tile's: L2-warm after the first fetch
+      issue_halo<KK::hbeg(J0), KK::hbeg(J0 + 1)>(a, lds, hp, hoff, hl, buf, q.ntile >= 0, 0, 4, 8, 8, q.nch * 32);
+#else
+      issue_halo<KK::hbeg(J0), KK::hbeg(J0 + 1)>(a, lds, hp, hoff, hl, buf, q.ntile >= 0, q.nn, q.nd0, q.nh0, q.nw0, q.nch * 32);
+#endif
+    } else halo_part<J0 + 1, NCB>(a, lds, hp, hoff, hl, buf, q, j);
+  }
+}
+
 // ST: this instantiation carries the output-statistics code (forward kernel of the 32-channel variant only: see stats_flush)
 template <int NCB, bool ST>
 __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y, int hl, int lane, int tile0, int tile_step, int tile_last) {
   using KK = K<NCB>;
   int hp[HPW];  // this lane's halo DMA pieces: (logical slot << 24) | (hd << 16) | (hh << 8) | hw, or -1
+  unsigned hoff[HPW];  // ... and their byte offsets from the halo origin voxel
 #pragma unroll
   for (int k = 0; k < HPW; ++k) {
     const int v = (hl + 4 * k) * 16 + (lane >> 2), p = lane & 3;
     const int hd = v / 100, rem = v - hd * 100, hh = rem / 10, hw = rem - hh * 10;
     hp[k] = v < HALO_VOX ? (((p ^ (hh & 3)) << 24) | (hd << 16) | (hh << 8) | hw) : -1;
+    // (lanes past the image fetch the origin voxel into LDS padding nobody reads -- on the interior path; the border path masks them)
+    hoff[k] = v < HALO_VOX ? (unsigned)(((hd * a.Hi + hh) * a.Wi + hw) * a.x_cs + (p ^ (hh & 3)) * 8) * 2u : 0u;
   }
   const bool has_res = a.res != nullptr;
   const bool resident = a.nchunks == 1 && KK::NG <= RD;  // the ring holds every group of the only chunk: load once
@@ -533,14 +666,26 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
   };
   Seq q;
   q.tile = tile0; q.ch = 0;
-  tile_origin(a.g, tile0, q.n, q.d0, q.h0, q.w0);
-  issue_halo(a, lds, hp, hl, 0, 1, q.n, q.d0, q.h0, q.w0, 0);
+  walk_init(q.walk, a.g, tile0, tile_step);
+  walk_origin(q.walk, a.g, q.n, q.d0, q.h0, q.w0);
+  issue_halo<0, HPW>(a, lds, hp, hoff, hl, 0, 1, q.n, q.d0, q.h0, q.w0, 0);
   issue_next_A();
   issue_next_A();  // two groups ahead
+  if (resident)    // ... or all of them: nothing publishes a group later (compute_top skips the inner barriers)
+    for (int g = 2; g < KK::NG; ++g) issue_next_A();
   wait_vm<0>();
-  __builtin_amdgcn_s_barrier();  // prologue
+  C27_BARRIER();  // prologue
   Epi<NCB> e;
-  e.active = 0; e.n = e.d0 = e.h0 = e.w0 = 0;
+  e.active = 0; e.full = 0; e.n = e.d0 = e.h0 = e.w0 = 0;
+  e.ybase = e.rbase = 0;
+  {
+    const int vl = lane / KK::PV, sidx = lane % KK::PV, row = vl >> 3, col = vl & 7;  // (pieces start at whole rows: v & (PV-1) == vl & (PV-1))
+    e.ylane = (unsigned)(((hl * a.Ho + row) * a.Wo + col) * a.y_cs + sidx * 8) * 2u;
+    e.rlane = (unsigned)(((hl * a.Ho + row) * a.Wo + col) * a.res_cs + sidx * 8) * 2u;
+    e.slane = (unsigned)(vl * KK::VOXP + ((sidx ^ (vl & (KK::PV - 1))) * 16));
+    e.yps = (unsigned)((8 / KK::PV) * a.Wo * a.y_cs) * 2u;
+    e.rps = (unsigned)((8 / KK::PV) * a.Wo * a.res_cs) * 2u;
+  }
 #pragma unroll
   for (int p = 0; p < KK::PV; ++p) e.res[p] = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
@@ -548,42 +693,57 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
   e.sn = -1;
   if (ST && a.stats) stats_zero<NCB>(a, y, hl, lane);
   int cur = 0;
+  [[maybe_unused]] unsigned long long hbw[4] = {0, 0, 0, 0}, hseg[4] = {0, 0, 0, 0};  // MI_C27_DIAG_BAR
   while (true) {
     seq_next(q, a, tile_step, tile_last);
     const bool epi = e.active != 0;  // wave-uniform
     // ---- top 0
-    wait_vm<0>();  // group 1's weights are this wave's youngest operation
-    __builtin_amdgcn_s_barrier();
+    if (!resident) wait_vm<0>();  // group 1's weights are this wave's youngest operation (resident: nothing to wait for, and the
+                                  // wait would sit out the completion of the previous tile's stores)
+    C27_BARRIER_T(hbw[0]);
+    { C27_T0();
     if (epi) stats_begin_tile<NCB, ST>(e, a, y, hl, lane);
     epi_issue_res<NCB>(e, a, y, hl, lane, epi && has_res);
     issue_next_A();
-    issue_halo(a, lds, hp, hl, cur ^ 1, q.ntile >= 0, q.nn, q.nd0, q.nh0, q.nw0, q.nch * 32);
-    // ---- tops 1 .. NG-2
+    halo_part<0, NCB>(a, lds, hp, hoff, hl, cur ^ 1, q, 0);
+    C27_T1(hseg[0]); }
+    // ---- tops 1 .. NG-2.  Issue order inside a top: weights of group j+2, halo part j, stores of slot j (after the barrier);
+    // at top j the weights issued at top j-1 must have landed, i.e. everything but the halo part and the stores of top j-1.
     for (int j = 1; j < KK::NG - 1; ++j) {
-      if (j == 1) wait_vm<HPW>();                 // younger than group 2's weights: the halo quarter
-      else if (epi) wait_vm<KK::PPT>();  // ... the stores of slot j-1
-      else wait_vm<0>();
-      __builtin_amdgcn_s_barrier();
+      if (!resident) {  // (resident weights: nothing to publish, nothing to wait for -- least of all the stores' completion)
+        const int hprev = KK::hbeg(j) - KK::hbeg(j - 1);  // (values of a small table: j is a loop counter)
+        wait_vm_dyn(hprev + ((epi && j >= 2) ? KK::PPT : 0));
+        C27_BARRIER_T(hbw[j == 1 ? 1 : 2]);
+      }
       issue_next_A();
-      if (epi) epi_slot<1, NCB, ST>(e, a, lds, y, hl, lane, j, has_res);
+      halo_part<1, NCB>(a, lds, hp, hoff, hl, cur ^ 1, q, j);
+      { C27_T0(); if (epi) epi_slot<1, NCB, ST>(e, a, lds, y, hl, lane, j, has_res); C27_T1(hseg[1]); }
     }
     // ---- top NG-1: the last store slot runs BEFORE the barrier (a single-chunk tile's compute waves overwrite the staging tile right
     // after it); the next image's halo and group NG's weights must have landed, the stores of the last two slots may fly
+    { C27_T0();
     if (epi) {
       epi_process<(KK::NG - 2) * KK::PPT, KK::PPT, NCB, ST>(e, a, lds, y, hl, lane, has_res);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done
       e.active = 0;
     }
+    C27_T1(hseg[2]); }
+    { C27_T0();
     if (epi) wait_vm<2 * KK::PPT>(); else wait_vm<0>();  // younger than group NG's weights: the stores of the last two slots
-    __builtin_amdgcn_s_barrier();
+    C27_T1(hseg[3]); }
+    C27_BARRIER_T(hbw[3]);
     issue_next_A();
-    if (q.ch == a.nchunks - 1 && !(a.dbg & 1)) { e.active = 1; e.n = q.n; e.d0 = q.d0; e.h0 = q.h0; e.w0 = q.w0; }
+    if (q.ch == a.nchunks - 1 && !(a.dbg & 1)) epi_begin_tile<NCB>(e, a, y, q.n, q.d0, q.h0, q.w0);
     if (q.ntile < 0) break;
     cur ^= 1;
     seq_advance(q);
   }
   wait_vm<0>();
-  __builtin_amdgcn_s_barrier();  // final: the last tile's staging is complete
+  C27_BARRIER();  // final: the last tile's staging is complete
+#ifdef MI_C27_DIAG_BAR
+  if ((a.dbg & 64) && blockIdx.x == 0 && blockIdx.y == 0 && hl == 0 && lane == 0)
+    for (int i = 0; i < 4; ++i) { g_c27_clk[8 + i] = hbw[i]; g_c27_clk[12 + i] = hseg[i]; }
+#endif
   if (e.active) {
     stats_begin_tile<NCB, ST>(e, a, y, hl, lane);
     epi_issue_res<NCB>(e, a, y, hl, lane, has_res);
@@ -629,10 +789,16 @@ int launch27(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), (size_t)KK::LDS_TOTAL, st, a);
   MI_CHECK_LAUNCH();
   if (a.dbg & 64) {  // diagnostic only: synchronises
-    unsigned long long h[4] = {0, 0, 0, 0};
+    unsigned long long h[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_c27_clk), sizeof(h));
     if (h[1]) fprintf(stderr, "[conv27<%d,%d>] main loop: %llu shader cycles in %.1f us -> %.0f MHz\n", NCB, FLIP, h[0], h[1] / 100.0, h[0] / (h[1] / 100.0));
+#ifdef MI_C27_DIAG_BAR
+    fprintf(stderr, "[conv27<%d,%d>] cycles inside barriers (top 0 / 1 / 2..NG-2 / NG-1): compute wave 0: %llu %llu %llu %llu   helper wave 4: %llu %llu %llu %llu\n", NCB,
+            FLIP, h[4], h[5], h[6], h[7], h[8], h[9], h[10], h[11]);
+    fprintf(stderr, "[conv27<%d,%d>] helper wave 4 segments: top-0 issue %llu, middle store slots %llu, last store slot %llu, final vmcnt wait %llu\n", NCB, FLIP, h[12],
+            h[13], h[14], h[15]);
+#endif
   }
   return 0;
 }

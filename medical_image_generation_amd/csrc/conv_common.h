@@ -78,6 +78,41 @@ static __device__ __forceinline__ void tile_origin(const Geom& g, int tile, int&
   d0 = td * g.TD; h0 = th * g.TH; w0 = tw * g.TW;
 }
 
+// The same walk, stepped without divisions.  A persistent workgroup visits tile0, tile0 + step, ...; tile_origin costs five integer
+// divisions by run-time values = ~150 VALU instructions even on wave-uniform operands, and in the role kernels every wave pays them
+// per tile out of the few vector-issue slots the MFMA stream leaves (measured in k_conv27: ~900 cycles per tile on every wave).
+// TileWalk keeps the mixed-radix digits of the tile index (w, row inside the h-block, depth, h-block, image) and adds the digits
+// of the step with carries: scalar adds and compares only.
+struct TileWalk {
+  int tw, hr, td, hbi, n;       // digits of the current tile
+  int s_tw, s_hr, s_td, s_hbi, s_n;  // digits of the step
+  int r_hr, r_hbi;              // radices that are not in Geom: rows per h-block, h-blocks
+};
+static __device__ __forceinline__ void walk_digits(const Geom& g, int hb, int nhb, int t, int& tw, int& hr, int& td, int& hbi, int& n) {
+  tw = t % g.tilesW; t /= g.tilesW;
+  hr = t % hb; t /= hb;
+  td = t % g.tilesD; t /= g.tilesD;
+  hbi = t % nhb;
+  n = t / nhb;
+}
+static __device__ __forceinline__ void walk_init(TileWalk& k, const Geom& g, int tile0, int step) {
+  k.r_hr = g.hb > 1 ? g.hb : g.tilesH;  // hb <= 1: one h-block of all rows = the plain (w, h, d) raster
+  k.r_hbi = g.tilesH / k.r_hr;
+  walk_digits(g, k.r_hr, k.r_hbi, tile0, k.tw, k.hr, k.td, k.hbi, k.n);
+  walk_digits(g, k.r_hr, k.r_hbi, step, k.s_tw, k.s_hr, k.s_td, k.s_hbi, k.s_n);
+}
+static __device__ __forceinline__ void walk_step(TileWalk& k, const Geom& g) {
+  int c;
+  k.tw += k.s_tw;          c = k.tw >= g.tilesW;  k.tw -= c ? g.tilesW : 0;
+  k.hr += k.s_hr + c;      c = k.hr >= k.r_hr;    k.hr -= c ? k.r_hr : 0;
+  k.td += k.s_td + c;      c = k.td >= g.tilesD;  k.td -= c ? g.tilesD : 0;
+  k.hbi += k.s_hbi + c;    c = k.hbi >= k.r_hbi;  k.hbi -= c ? k.r_hbi : 0;
+  k.n += k.s_n + c;
+}
+static __device__ __forceinline__ void walk_origin(const TileWalk& k, const Geom& g, int& n, int& d0, int& h0, int& w0) {
+  n = k.n; d0 = k.td * g.TD; h0 = (k.hbi * k.r_hr + k.hr) * g.TH; w0 = k.tw * g.TW;
+}
+
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 static __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
