@@ -61,10 +61,13 @@ int mi_gn_stats_from_partial(const float* partial_a, int chunks_a, int Ca, const
 /* y = (silu?)(x*scale+shift) */
 int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y, int y_cstride, int N, int64_t V, int C, int silu,
                 hipStream_t stream);
-/* g = dL/d(output of norm[+silu]);  dx = GN/SiLU backward (+ add);  dgamma/dbeta are ACCUMULATED (fp32);  coef: [N][C][3] scratch */
+/* g = dL/d(output of norm[+silu]);  dx = GN/SiLU backward (+ add + add2);  dgamma/dbeta are ACCUMULATED (fp32);  coef: [N][C][3] scratch.
+ * add / add2 (bf16, own voxel pitches, either may be null; add2 only with add): the other pending branches of x's gradient -- the
+ * residual path and, for a tensor that is also a skip connection, its slice of d(concat) -- summed in fp32 inside the same pass
+ * (autograd's gradient accumulation of ResnetBlock.forward's `x`, UNet:674-701 / 1263). */
 int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N, int64_t V, int C, int G, const float* gamma,
-              const float* scale_shift, const float* mean_rstd, int silu, const void* add, int add_cstride, void* dx, int dx_cstride,
-              float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, hipStream_t stream);
+              const float* scale_shift, const float* mean_rstd, int silu, const void* add, int add_cstride, const void* add2, int add2_cstride,
+              void* dx, int dx_cstride, float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
 /* ---- aten::convolution / convolution_backward: every Convolution(conv_only=True) -> nn.Conv{2,3}d, UNet:510,557,630,650,664,
  *      1820,1935; AEKL:67-86,121,158-187,372,454,523,606,723-749.  Per-axis (kernel,stride,padding) in {(3,1,1),(3,2,1),(1,1,0)}

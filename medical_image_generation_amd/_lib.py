@@ -33,7 +33,7 @@ _SIGS = {
     "mi_gn_stats": [_p, _i, _i, _l, _i, _i, _f, _p, _p, _p, _p, _p, _l, _p],
     "mi_gn_stats_from_partial": [_p, _i, _i, _p, _i, _i, _i, _l, _i, _f, _p, _p, _p, _p, _p],
     "mi_gn_apply": [_p, _i, _p, _p, _i, _i, _l, _i, _i, _p],
-    "mi_gn_bwd": [_p, _i, _p, _i, _i, _l, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _l, _p],
+    "mi_gn_bwd": [_p, _i, _p, _i, _i, _l, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _l, _p],
     "mi_conv_plan_create": [C.POINTER(_p), _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "mi_conv_plan_destroy": [_p],
     "mi_conv_plan_out_dims": [_p, C.POINTER(_i)],

@@ -802,6 +802,14 @@ __global__ void __launch_bounds__(512, 2) k_conv_wgrad(WgradArgs w) {
 // (buffer_load ... lds; the hardware range check supplies zero padding and the ragged volume edge) one tile ahead, and there is
 // ONE s_barrier per tile: it publishes tile i+1's images (loaders wait vmcnt(0) first) and frees tile i's buffers.
 typedef __attribute__((address_space(3))) void lds_void_t;
+#ifdef MI_WG2_DIAG_BAR  // ablation build: where do the waves of workgroup 0 spend their cycles? (tools/diag/wg2_diag.py)
+__device__ unsigned long long g_wg2_clk[8];
+#define WG2_T0() const unsigned long long tt0__ = __builtin_amdgcn_s_memtime()
+#define WG2_T1(acc) (acc) += __builtin_amdgcn_s_memtime() - tt0__
+#else
+#define WG2_T0() do {} while (0)
+#define WG2_T1(acc) do {} while (0)
+#endif
 
 template <int MAXP>
 struct DmaPieces {
@@ -967,16 +975,26 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     if (NB == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // prologue: tile 0 has landed
+    [[maybe_unused]] unsigned long long lseg[3] = {0, 0, 0}, lt0 = 0;
+#ifdef MI_WG2_DIAG_BAR
+    lt0 = __builtin_amdgcn_s_memtime();
+#endif
     while (true) {
       const int next = tile + tstep;
       const int free_slot = slot == 0 ? NB - 1 : slot - 1;  // released by the barrier that ended the previous iteration
-      request(tile + (NB - 1) * tstep, free_slot);
-      wait_next();
-      __builtin_amdgcn_s_barrier();
+      { WG2_T0(); request(tile + (NB - 1) * tstep, free_slot); WG2_T1(lseg[0]); }
+      { WG2_T0(); wait_next(); WG2_T1(lseg[1]); }
+      { WG2_T0(); __builtin_amdgcn_s_barrier(); WG2_T1(lseg[2]); }
       if (next >= tend) break;
       tile = next;
       slot = slot + 1 == NB ? 0 : slot + 1;
     }
+#ifdef MI_WG2_DIAG_BAR
+    if (blockIdx.x == 0 && wave == 8 && lane == 0) {
+      g_wg2_clk[0] = __builtin_amdgcn_s_memtime() - lt0;
+      g_wg2_clk[1] = lseg[0]; g_wg2_clk[2] = lseg[1]; g_wg2_clk[3] = lseg[2];
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (ksplit) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }  // the compute waves' fold
     return;
@@ -1031,7 +1049,12 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     }
   }
   __builtin_amdgcn_s_barrier();  // prologue: tile 0 is in slot 0
+  [[maybe_unused]] unsigned long long cbar = 0, ct0 = 0, ntl = 0;
+#ifdef MI_WG2_DIAG_BAR
+  ct0 = __builtin_amdgcn_s_memtime();
+#endif
   while (true) {
+    ++ntl;
     if (cs_wave && n != cs_n) {
       cs_flush(cs_n);
       cs_n = n;
@@ -1065,7 +1088,7 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
         }
       }
     }
-    __builtin_amdgcn_s_barrier();  // this tile's buffers are free; the next tile's images have landed
+    { WG2_T0(); __builtin_amdgcn_s_barrier(); WG2_T1(cbar); }  // this tile's buffers are free; the next tile's images have landed
     const int next = tile + tstep;
     if (next >= tend) break;
     tile = next;
@@ -1073,6 +1096,9 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     walk_step(walk, g);
     walk_origin(walk, g, n, d0, h0, w0);
   }
+#ifdef MI_WG2_DIAG_BAR
+  if (blockIdx.x == 0 && wave == 0 && lane == 0) { g_wg2_clk[4] = __builtin_amdgcn_s_memtime() - ct0; g_wg2_clk[5] = cbar; g_wg2_clk[6] = ntl; g_wg2_clk[7] = nt; }
+#endif
   if (cs_wave) cs_flush(cs_n);
 
   float* out = w.part + (int64_t)split * w.split_stride + w.pair_off[pair];
@@ -1975,6 +2001,15 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
       }
       if (geo3) hipLaunchKernelGGL(k_conv_wgrad2<true>, grid, dim3(768), lds2, st, w);
       else hipLaunchKernelGGL(k_conv_wgrad2<false>, grid, dim3(768), lds2, st, w);
+#ifdef MI_WG2_DIAG_BAR
+      {
+        unsigned long long h[8];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wg2_clk), sizeof(h));
+        fprintf(stderr, "[wgrad2] workgroup 0: compute wave 0: %llu cycles over %llu tiles (%llu taps), %llu inside the barrier | loader wave 8: %llu cycles = issue %llu + vmcnt wait %llu + barrier %llu\n",
+                h[4], h[6], h[7], h[5], h[0], h[1], h[2], h[3]);
+      }
+#endif
       launch_wgrad_reduce(P->d_part, P->wg_split_stride, P->wg_nsplit, P->d_uitems, P->wg_nitems, dw, P->Cout, P->Cin, P->KT, P->d_pair_off,
                           P->wg.ny * P->wg.nchunks,
                           CsReduce{w.cs_part ? P->d_cspart : nullptr, P->wg_nsplit, P->N, P->Cout, dy_colsum, dy_colsum_stride, 0}, st);

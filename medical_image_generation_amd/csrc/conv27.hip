@@ -365,6 +365,7 @@ __device__ __forceinline__ void compute_role(const ConvArgs& a, char* lds, int y
     else taps<0, 0, NCB, FLIP>(s, lane);
     par ^= 1;
     if (q.ch == a.nchunks - 1) {  // tile finished (the next image's first fragments are already on their way)
+      if (s.resident) C27_BARRIER_T(s.bw[1]);  // the helper waves have read the previous tile out of the staging tile (helper_role)
       if (!(a.dbg & 1)) stage_acc<NCB>(s, lds, wave, lane);
       if (q.ntile >= 0 && q.nn != s.av_n) {  // image index changed: once in thousands of tiles
         load_av<NCB>(s, a, lds, y, wave, lane, q.nn);
@@ -697,9 +698,37 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
   while (true) {
     seq_next(q, a, tile_step, tile_last);
     const bool epi = e.active != 0;  // wave-uniform
+    if (resident) {
+      // Resident weights: three barriers per image and the two jobs of this wave under different ones.  The halo of the next image
+      // is issued after B0 and must have landed at the top-(NG-1) barrier (the compute waves prefetch their first fragments across
+      // the image boundary); the previous tile's staging is stored AFTER that barrier and released by a third one that the compute
+      // waves pass just before they overwrite the staging tile, a tap group later.  With both jobs due at the same barrier the
+      // helpers were the critical path (measured, 32->32 @128^3: ~2000 cycles to issue 10 LDS-DMA pieces beside the MFMA stream +
+      // ~1450 for the stores, against ~2300-2900 for the compute waves' two tap groups: they waited 16-23 % of the kernel there).
+      C27_BARRIER_T(hbw[0]);
+      { C27_T0();
+      if (epi) stats_begin_tile<NCB, ST>(e, a, y, hl, lane);
+      epi_issue_res<NCB>(e, a, y, hl, lane, epi && has_res);
+      halo_part<0, NCB>(a, lds, hp, hoff, hl, cur ^ 1, q, 0);
+      C27_T1(hseg[0]); }
+      { C27_T0(); wait_vm<0>(); C27_T1(hseg[3]); }  // (the previous tile's stores are a whole image old)
+      C27_BARRIER_T(hbw[3]);
+      { C27_T0();
+      if (epi) {
+        epi_process<0, KK::PV, NCB, ST>(e, a, lds, y, hl, lane, has_res);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done
+        e.active = 0;
+      }
+      C27_T1(hseg[2]); }
+      C27_BARRIER_T(hbw[1]);
+      if (q.ch == a.nchunks - 1 && !(a.dbg & 1)) epi_begin_tile<NCB>(e, a, y, q.n, q.d0, q.h0, q.w0);
+      if (q.ntile < 0) break;
+      cur ^= 1;
+      seq_advance(q);
+      continue;
+    }
     // ---- top 0
-    if (!resident) wait_vm<0>();  // group 1's weights are this wave's youngest operation (resident: nothing to wait for, and the
-                                  // wait would sit out the completion of the previous tile's stores)
+    wait_vm<0>();  // group 1's weights are this wave's youngest operation
     C27_BARRIER_T(hbw[0]);
     { C27_T0();
     if (epi) stats_begin_tile<NCB, ST>(e, a, y, hl, lane);
@@ -710,11 +739,9 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
     // ---- tops 1 .. NG-2.  Issue order inside a top: weights of group j+2, halo part j, stores of slot j (after the barrier);
     // at top j the weights issued at top j-1 must have landed, i.e. everything but the halo part and the stores of top j-1.
     for (int j = 1; j < KK::NG - 1; ++j) {
-      if (!resident) {  // (resident weights: nothing to publish, nothing to wait for -- least of all the stores' completion)
-        const int hprev = KK::hbeg(j) - KK::hbeg(j - 1);  // (values of a small table: j is a loop counter)
-        wait_vm_dyn(hprev + ((epi && j >= 2) ? KK::PPT : 0));
-        C27_BARRIER_T(hbw[j == 1 ? 1 : 2]);
-      }
+      const int hprev = KK::hbeg(j) - KK::hbeg(j - 1);  // (values of a small table: j is a loop counter)
+      wait_vm_dyn(hprev + ((epi && j >= 2) ? KK::PPT : 0));
+      C27_BARRIER_T(hbw[j == 1 ? 1 : 2]);
       issue_next_A();
       halo_part<1, NCB>(a, lds, hp, hoff, hl, cur ^ 1, q, j);
       { C27_T0(); if (epi) epi_slot<1, NCB, ST>(e, a, lds, y, hl, lane, j, has_res); C27_T1(hseg[1]); }

@@ -292,8 +292,8 @@ __global__ void __launch_bounds__(256) k_gn_bwd_finalize(const float* __restrict
 template <bool SILU>
 __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                      const float* __restrict__ scale_shift, const float* __restrict__ coef,
-                                                     const bf16* __restrict__ add, int acs, bf16* __restrict__ dx, int dcs, int C8,
-                                                     int64_t V) {
+                                                     const bf16* __restrict__ add, int acs, const bf16* __restrict__ add2, int a2cs,
+                                                     bf16* __restrict__ dx, int dcs, int C8, int64_t V) {
   const int C = C8 * 8;
   const int tid = blockIdx.x * kT + threadIdx.x;
   const int cg = tid % C8, R = gridDim.x * kT / C8;
@@ -308,9 +308,10 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
   const bf16* xb = x + n * V * xcs + cg * 8;
   const bf16* gb = g + n * V * gcs + cg * 8;
   const bf16* ab = add ? add + n * V * acs + cg * 8 : nullptr;
+  const bf16* a2b = add2 ? add2 + n * V * a2cs + cg * 8 : nullptr;  // second pending branch of x's gradient (e.g. a slice of d(concat))
   bf16* db = dx + n * V * dcs + cg * 8;
   for (int64_t v = tid / C8; v < V; v += 2 * (int64_t)R) {
-    u32x4 rx[2], rg[2], ra[2];
+    u32x4 rx[2], rg[2], ra[2], ra2[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int64_t vk = v + k * (int64_t)R;
@@ -318,6 +319,7 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
         rx[k] = *(const u32x4*)(xb + vk * xcs);
         rg[k] = *(const u32x4*)(gb + vk * gcs);
         if (ab) ra[k] = *(const u32x4*)(ab + vk * acs);
+        if (a2b) ra2[k] = *(const u32x4*)(a2b + vk * a2cs);
       }
     }
 #pragma unroll
@@ -333,6 +335,11 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
       }
       if (ab) {
         F8 fa = unpack8(ra[k]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.v[j] += fa.v[j];
+      }
+      if (a2b) {
+        F8 fa = unpack8(ra2[k]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.v[j] += fa.v[j];
       }
@@ -407,9 +414,10 @@ int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y,
 }
 
 int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N, int64_t V, int C, int G, const float* gamma,
-              const float* scale_shift, const float* mean_rstd, int silu, const void* add, int add_cstride, void* dx, int dx_cstride,
-              float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, hipStream_t st) {
-  if (bad_c(C, G) || N <= 0 || V <= 0 || (x_cstride & 7) || (g_cstride & 7) || (dx_cstride & 7) || (add && (add_cstride & 7)))
+              const float* scale_shift, const float* mean_rstd, int silu, const void* add, int add_cstride, const void* add2, int add2_cstride,
+              void* dx, int dx_cstride, float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+  if (bad_c(C, G) || N <= 0 || V <= 0 || (x_cstride & 7) || (g_cstride & 7) || (dx_cstride & 7) || (add && (add_cstride & 7)) ||
+      (add2 && (!add || (add2_cstride & 7))))
     return MI_ERR_BAD_ARG;
   if (workspace_bytes < mi_gn_workspace_bytes(N, V, C)) return MI_ERR_BAD_ARG;
   int64_t vc = pick_vchunk(V);
@@ -423,7 +431,7 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   int64_t grid = apply_grid(V * (C / 8), C / 8, N);
   auto ka = silu ? k_gn_bwd_apply<true> : k_gn_bwd_apply<false>;
   hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift, coef,
-                     (const bf16*)add, add_cstride, (bf16*)dx, dx_cstride, C / 8, V);
+                     (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V);
   MI_CHECK_LAUNCH();
   return 0;
 }

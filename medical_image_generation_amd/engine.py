@@ -102,14 +102,36 @@ class Tape:
     def record(self, fn):
         self.fns.append(fn)
 
+    # A tensor with two consumers (a ResnetBlock input: norm1 path + residual; a skip: next layer + its slice of d(concat)) collects
+    # its gradient branches here.  Two branches stay a PAIR: the GroupNorm backward that consumes them (take2) sums them in fp32 inside
+    # its own pass (mi_gn_bwd add / add2) -- the separate add kernel of a skip at 128^3 cost 77 us plus 65-79 us to densify the concat
+    # slice first.  Anyone else (take) gets the sum; a third branch folds the pair.
     def take(self, t):
-        return self.grads.pop(id(t), None)
+        g = self.grads.pop(id(t), None)
+        return ops.add(g[0], g[1]) if isinstance(g, tuple) else g
+
+    def take2(self, t):
+        """(branch, second branch or None) -- for consumers that can add two streams themselves."""
+        g = self.grads.pop(id(t), None)
+        return g if isinstance(g, tuple) else (g, None)
 
     def put(self, t, g):
-        """grad(t) += g through our add kernel."""
+        """grad(t) += g."""
         cur = self.grads.get(id(t))
-        self.grads[id(t)] = g if cur is None else ops.add(cur, g)
+        if cur is None:
+            self.grads[id(t)] = g
+        elif isinstance(cur, tuple):
+            self.grads[id(t)] = ops.add(ops.add(cur[0], cur[1]), g)
+        else:
+            self.grads[id(t)] = (cur, g)
         self.keep.append(t)
+
+    def move(self, t, other: "Tape"):
+        """Hand t's pending gradient (a pair stays a pair) to another tape."""
+        g = self.grads.pop(id(t), None)
+        if g is not None:
+            other.grads[id(t)] = g
+            other.keep.append(t)
 
     def backward(self, out, dout):
         self.put(out, dout)
@@ -249,9 +271,9 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
             if need_dx:
                 g = plan.dgrad(dy)
                 if norm is not None:
-                    other = tape.take(x)
+                    other, other2 = tape.take2(x)
                     dx = ops.gn_bwd(g, x, norm, ctx.p(norm.name + ".weight"), silu, ctx.g(norm.name + ".weight"),
-                                    ctx.g(norm.name + ".bias"), add=other)
+                                    ctx.g(norm.name + ".bias"), add=other, add2=other2)
                     tape.grads[id(x)] = dx
                     tape.keep.append(x)
                 else:
@@ -299,10 +321,7 @@ def checkpoint(ctx: Ctx, fn, x):
         inner.packed, inner.sums, inner.cat_parts = ctx.packed, ctx.sums, ctx.cat_parts
         y2 = fn(inner, x)
         it = inner.tape
-        pending = tape.take(x)
-        if pending is not None:
-            it.grads[id(x)] = pending
-            it.keep.append(x)
+        tape.move(x, it)  # (a pending pair stays a pair: the inner GroupNorm backward must see what the stored-activation path sees)
         it.backward(y2, dy)
         g = it.take(x)
         if g is not None:
@@ -341,8 +360,9 @@ def gn_act(ctx: Ctx, x, st, silu):
             g = tape.take(y)
             if g is None:
                 return
-            other = tape.take(x)
-            dx = ops.gn_bwd(g, x, st, ctx.p(st.name + ".weight"), silu, ctx.g(st.name + ".weight"), ctx.g(st.name + ".bias"), add=other)
+            other, other2 = tape.take2(x)
+            dx = ops.gn_bwd(g, x, st, ctx.p(st.name + ".weight"), silu, ctx.g(st.name + ".weight"), ctx.g(st.name + ".bias"), add=other,
+                            add2=other2)
             tape.grads[id(x)] = dx
             tape.keep.append(x)
 
@@ -502,8 +522,7 @@ def _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy,
     dxn = torch.empty(x.shape, dtype=BF16, device=dev)
     _gemm(dqkv, 3 * c, 0, 0, wqkv_t, 3 * c, 0, 0, dxn, c, 0, 0, b * s, c, 3 * c, 1, 1)
     other = tape.take(x)
-    add = dy if other is None else ops.add(other, dy)
-    dx = ops.gn_bwd(dxn, x, st, ctx.p(pre + "norm.weight"), False, ctx.g(pre + "norm.weight"), ctx.g(pre + "norm.bias"), add=add)
+    dx = ops.gn_bwd(dxn, x, st, ctx.p(pre + "norm.weight"), False, ctx.g(pre + "norm.weight"), ctx.g(pre + "norm.bias"), add=dy, add2=other)
     tape.grads[id(x)] = dx
     tape.keep.append(x)
 

@@ -183,15 +183,19 @@ def gn_apply(x, st: GNStats, silu: bool):
     return y
 
 
-def gn_bwd(g, x, st: GNStats, gamma, silu: bool, dgamma, dbeta, add=None):
-    """g = dL/d(act(GN(x))) -> dL/dx (+ add); dgamma/dbeta (fp32) are accumulated in place."""
+def gn_bwd(g, x, st: GNStats, gamma, silu: bool, dgamma, dbeta, add=None, add2=None):
+    """g = dL/d(act(GN(x))) -> dL/dx (+ add + add2: other pending branches of x's gradient, views allowed); dgamma/dbeta (fp32) are
+    accumulated in place."""
+    if add is None and add2 is not None:
+        add, add2 = add2, None
     n, v, c = _vox(x)
     dx = torch.empty(x.shape, dtype=BF16, device=x.device)
     coef = torch.empty((n, c, 3), dtype=F32, device=x.device)
     nb = _lib.call_raw("mi_gn_workspace_bytes", n, v, c)
     ws = _workspace(nb, x.device)
     call("mi_gn_bwd", ptr(g), _cs(g), ptr(x), _cs(x), n, v, c, st.groups, ptr(gamma), ptr(st.scale_shift), ptr(st.mean_rstd),
-         int(silu), ptr(add), _cs(add) if add is not None else 0, ptr(dx), c, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(ws), ws.numel())
+         int(silu), ptr(add), _cs(add) if add is not None else 0, ptr(add2), _cs(add2) if add2 is not None else 0, ptr(dx), c, ptr(dgamma),
+         ptr(dbeta), ptr(coef), ptr(ws), ws.numel())
     return dx
 
 

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from medical_image_generation_amd import _lib
     lib = _lib.load()  # raises if the .so is missing
-    assert lib.mi_abi_version() == 2
+    assert lib.mi_abi_version() == 3
     hdr = open(os.path.join(ROOT, "include", "medimgen_hip.h")).read()
     declared = set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.exported_symbols())
