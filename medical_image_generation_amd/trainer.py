@@ -7,8 +7,9 @@ No torch autograd and no torch compute kernels in the step: the tape engine driv
 optimizer is one fused launch over the flat parameter arena, and the whole step can be captured in a hipGraph
 (`capture=True`) and replayed, which removes the Python / launch overhead of ~600 kernel launches.
 
-`AETrainer` is the same thing for the generator step of train_autoencoder.AutoEncoder.train_one_epoch (T-AE:406-435)
-without its third-party perceptual/adversarial terms: encode -> sample -> decode -> L1 + kl_weight * KL -> backward -> Adam.
+`AETrainer` is the same thing for the generator step of train_autoencoder.AutoEncoder.train_one_epoch (T-AE:406-435):
+encode -> sample -> decode -> L1 + kl_weight * KL (+ the caller's perceptual / adversarial terms through `extra_loss`, evaluated by
+torch autograd on the reconstruction: those networks are third-party torch modules) -> backward -> Adam.
 
 Data parallelism: one process per GPU; the trainable prefix of the flat gradient arena is all-reduced
 (average) over RCCL in a few large buckets -- statically unused `proj_attn.*` tensors live outside that prefix.
@@ -333,13 +334,24 @@ class LDMTrainer(DDPMTrainer):
 class AETrainer(_ArenaTrainer):
     """step(images, eps): images fp32 NCDHW, eps fp32 latent-shaped NCDHW (the torch.randn_like of AEKL:786-787 made an
     input so that a captured graph sees fresh noise and tests can pin it).  Defaults are the reference's generator
-    optimizer (Adam, lr 5e-5, grad_clip_max_norm 1; T-AE:428-434, 470) and 3-D kl_weight (CFG:995-1026)."""
+    optimizer (Adam, lr 5e-5, grad_clip_max_norm 1; T-AE:428-434, 470) and 3-D kl_weight (CFG:995-1026).
+
+    extra_loss: the generator step's third-party terms (T-AE:411-421: `perceptual_loss(recon, images) * perc_weight` and, after the
+    warm-up epochs, `adv_loss(discriminator(recon)[-1], target_is_real=True, for_discriminator=False) * adv_weight`).  A callable
+    (reconstruction fp32 NCDHW with requires_grad, images) -> scalar torch loss; it runs under torch autograd on the GPU and its
+    gradient with respect to the reconstruction joins the L1 gradient before the HIP backward.  The networks inside it
+    (`generative`'s PatchDiscriminator / PerceptualLoss with downloaded weights) stay the user's torch modules -- they are not
+    rebuilt here.  `reconstruction` (fp32 NCDHW, detached) holds the last step's output for the caller's discriminator step
+    (T-AE:371-397), which is plain torch on the caller's side."""
 
     def __init__(self, model, lr=5e-5, optimizer="Adam", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
-                 kl_weight=1e-7, process_group=None, bucket_mb=64, device=None, grad_accumulate_step=1):
+                 kl_weight=1e-7, process_group=None, bucket_mb=64, device=None, grad_accumulate_step=1, extra_loss=None):
         super().__init__(model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device,
                          grad_accumulate_step)
         self.kl_weight = float(kl_weight)
+        self.extra_loss = extra_loss
+        self.reconstruction = None
+        self.extra_loss_value = None
 
     def _forward(self, images, eps):
         m, a = self.model, self.arena
@@ -369,4 +381,13 @@ class AETrainer(_ArenaTrainer):
         recon = m._decode_run(ctx, z, True)
         drecon = torch.empty_like(recon)
         call("mi_l1_fwd_bwd", ptr(recon), ptr(images), ptr(drecon), ptr(self.loss), n, recon.shape[-1], v, 1)
+        if self.extra_loss is not None:
+            rec = ops.to_channels_first(recon, len(sp)).requires_grad_(True)
+            with torch.enable_grad():
+                extra = self.extra_loss(rec, images)
+                (g,) = torch.autograd.grad(extra, rec)
+            self.extra_loss_value = extra.detach()
+            self.loss += self.extra_loss_value.to(self.loss.dtype).reshape(self.loss.shape)
+            drecon = ops.add(drecon, ops.to_channels_last(g))
+            self.reconstruction = rec.detach()
         return tape, recon, drecon

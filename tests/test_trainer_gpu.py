@@ -117,6 +117,71 @@ def test_ae_three_train_steps(name, graph):
     assert cos >= 0.85 and abs(float(upd_hip.norm()) / float(upd_ref.norm()) - 1) <= 0.05
 
 
+def test_ae_extra_loss_hook_matches_oracle():
+    """The generator step with the reference's third-party terms (T-AE:411-421) supplied through AETrainer(extra_loss=...): a small
+    torch patch discriminator with the least-squares generator loss (PatchAdversarialLoss(criterion="least_squares"): mean((D(x) - 1)^2))
+    and a feature-space "perceptual" term.  The hook's gradient must reach the AE parameters exactly as autograd delivers it in the
+    oracle composition: compared through the DIFFERENCE it makes to the parameter gradient (with the hook minus without)."""
+    from medical_image_generation_amd.autoencoderkl import AutoencoderKL
+    from medical_image_generation_amd.trainer import AETrainer
+    c = cases.AEKL_CASES["aekl_c3a"]
+    ref = nets.AutoencoderKL(**c["kwargs"])
+    sd0 = synth.state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, S)
+    ref.load_state_dict(sd0)
+    net = AutoencoderKL(**c["kwargs"])
+    net.load_state_dict(sd0)
+    net = net.cuda()
+    torch.manual_seed(4)
+    disc = torch.nn.Sequential(torch.nn.Conv3d(1, 8, 4, 2, 1), torch.nn.LeakyReLU(0.2), torch.nn.Conv3d(8, 1, 4, 1, 1))
+    feat = torch.nn.Sequential(torch.nn.Conv3d(1, 4, 3, 1, 1), torch.nn.ReLU(), torch.nn.AvgPool3d(2))
+
+    def extra(d, f):
+        def fn(rec, images):
+            return 2.0 * ((d(rec) - 1.0) ** 2).mean() + 20.0 * ((f(rec) - f(images)) ** 2).mean()  # (weights that put the hook gradient above the bf16 quantum of the L1 sign gradient)
+        return fn
+
+    x = synth.ellipsoid_volume(S, "x", c["shape"])
+    with torch.no_grad():
+        zshape = tuple(ref.encode(x)[0].shape)
+    eps = synth.tensor(S, "eps0", zshape)
+    names = [n for n, p in ref.named_parameters()]
+
+    def ref_grads(with_hook):
+        ref.zero_grad(set_to_none=True)
+        loss, recon, _, _ = step.ae_loss(ref, x, eps, 1e-3)
+        if with_hook:
+            loss = loss + extra(disc, feat)(recon.float(), x)
+        loss.backward()
+        return float(loss.detach()), torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for _, p in ref.named_parameters()])
+
+    import copy
+    dg, fg = copy.deepcopy(disc).cuda(), copy.deepcopy(feat).cuda()
+    for m in (dg, fg):
+        for p in m.parameters():
+            p.requires_grad_(False)  # T-AE:399-400: the discriminator is frozen in the generator step
+
+    def hip_grads(with_hook):
+        tr = AETrainer(net, lr=cases.STEP_LR, kl_weight=1e-3, max_grad_norm=1.0, extra_loss=extra(dg, fg) if with_hook else None)
+        tr.forward_backward(x.cuda(), eps.cuda())
+        g = torch.cat([tr.arena.gview(n).cpu().flatten() for n in names])
+        if with_hook:
+            assert tr.reconstruction is not None and tuple(tr.reconstruction.shape) == tuple(x.shape)
+        return float(tr.loss), g
+
+    l0r, g0r = ref_grads(False)
+    l1r, g1r = ref_grads(True)
+    l0h, g0h = hip_grads(False)
+    l1h, g1h = hip_grads(True)
+    dr, dh = g1r - g0r, g1h - g0h
+    cos = float(torch.dot(dr, dh) / (dr.norm() * dh.norm()))
+    ratio = float(dh.norm() / dr.norm())
+    print(f"\n[AE extra_loss hook] loss {l1h:.5f} vs {l1r:.5f} (without: {l0h:.5f} vs {l0r:.5f}); hook gradient cosine {cos:.4f}, norm ratio {ratio:.3f}")
+    assert abs(l1h - l1r) <= 2e-2 * abs(l1r) and abs((l1h - l0h) - (l1r - l0r)) <= 5e-2 * abs(l1r - l0r)
+    assert float(dr.norm()) > 1e-3 * float(g0r.norm())  # the hook matters in this set-up
+    # the difference of two bf16 backward passes, each carrying the sign-gradient noise of L1: cosine, not element-wise
+    assert cos >= 0.9 and abs(ratio - 1) <= 0.1
+
+
 def test_v_prediction_step_matches_oracle():
     """prediction_type = "v_prediction" (train_ldm.py:163-165): the target is scheduler.get_velocity(x0, noise, t)."""
     from medical_image_generation_amd.trainer import DDPMSchedule, DDPMTrainer
