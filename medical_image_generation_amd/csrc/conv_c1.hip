@@ -379,19 +379,28 @@ __global__ void __launch_bounds__(256) k_c1_wgrad(C1WgArgs a) {
 // dw[c][t] += sum_slabs part[c * 32 + t] (t < 27);  colsum_m[c] += column 27;  colsum_s[0] += the s sums
 __global__ void __launch_bounds__(256) k_c1_wgrad_reduce(const float* __restrict__ part, int nslab, int slab, int C, float* __restrict__ dw,
                                                          float* __restrict__ colsum_m, float* __restrict__ colsum_s) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i > C * 32) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int k = 0;
+  // 32 outputs per block, the slabs dealt over 8 thread groups (one thread walking all 512 slabs is 128 dependent load latencies)
+  __shared__ float red[8][32];
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+  const bool live = i <= C * 32;
   const int idx = i < C * 32 ? i : slab - 32;
-  for (; k + 3 < nslab; k += 4) {
-    s0 += part[(int64_t)k * slab + idx];
-    s1 += part[(int64_t)(k + 1) * slab + idx];
-    s2 += part[(int64_t)(k + 2) * slab + idx];
-    s3 += part[(int64_t)(k + 3) * slab + idx];
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (live) {
+    int k = g;
+    for (; k + 24 < nslab; k += 32) {
+      s0 += part[(int64_t)k * slab + idx];
+      s1 += part[(int64_t)(k + 8) * slab + idx];
+      s2 += part[(int64_t)(k + 16) * slab + idx];
+      s3 += part[(int64_t)(k + 24) * slab + idx];
+    }
+    for (; k < nslab; k += 8) s0 += part[(int64_t)k * slab + idx];
   }
-  for (; k < nslab; ++k) s0 += part[(int64_t)k * slab + idx];
-  const float v = (s0 + s1) + (s2 + s3);
+  red[g][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (g != 0 || !live) return;
+  float v = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v += red[j][threadIdx.x];
   if (i == C * 32) { if (colsum_s) colsum_s[0] += v; return; }
   const int c = i >> 5, tp = i & 31;
   if (tp < 27) dw[c * 27 + tp] += v;
@@ -486,7 +495,7 @@ int mi_launch_c1_wgrad(const void* m, int m_cs, const void* s1, int s_cs, float*
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, st, a);
   }
   const int slab = ncb * 1024 + 32;
-  hipLaunchKernelGGL(k_c1_wgrad_reduce, dim3((C * 32 + 1 + 255) / 256), dim3(256), 0, st, part, grid, slab, C, dw, colsum_m, colsum_s);
+  hipLaunchKernelGGL(k_c1_wgrad_reduce, dim3((C * 32 + 1 + 31) / 32), dim3(256), 0, st, part, grid, slab, C, dw, colsum_m, colsum_s);
   MI_CHECK_LAUNCH();
   return 0;
 }
