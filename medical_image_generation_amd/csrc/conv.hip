@@ -424,6 +424,7 @@ struct WgradArgs {
   const bf16* dy; int dy_cs;
   unsigned dy_bytes;  // size of dy for its buffer descriptor (LDS-DMA kernel)
   int nbuf;           // LDS-DMA kernel: image ring depth (2; 4 for 1x1 pairs)
+  int flags;          // LDS-DMA kernel: tiles handed over by LDS counters instead of a barrier per tile (MI_WGRAD_FLAGS, default 1)
   float* cs_part;     // [nsplit][N][Cout] per-workgroup column sums (tap pairs): plain stores, folded by cs_reduce_block (trailing blocks of the reduce launch) -- 256 workgroups
                       // adding to the same 128-byte line with atomics serialise for tens of microseconds
   float* part;        // [nsplit][npairs][MAXTAPS? -> ntaps_of_pair][32][32] laid out by pair_off
@@ -904,6 +905,20 @@ __device__ __forceinline__ void dma_issue_y(const DmaPieces<MAXP>& d, const Wgra
   }
 }
 
+// Tile hand-off by counters in LDS instead of a workgroup barrier per tile (w.flags).  The barrier made all eight compute waves wait
+// for the slowest of them at every tile (measured: 15 % of the kernel inside it, profiles/r02f_wgrad2_barrier_cycles.log) although
+// nothing couples them: a compute wave only needs "tile i has landed" (ready[slot], +1 per loader wave behind its vmcnt wait) and a
+// loader only needs "all eight compute waves are done with the tile whose slot I am about to refill" (freed[slot], +1 per compute
+// wave).  LDS operations of all waves go through one in-order pipeline, so a counter update issued after the data is in LDS (loader:
+// after its vmcnt wait) or after the reads have returned (compute: its MFMAs consumed them) is seen no earlier than that data.
+__device__ __forceinline__ void flag_wait(volatile unsigned* f, unsigned target) {
+  while (*f < target) __builtin_amdgcn_s_sleep(1);
+  asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void flag_bump(unsigned* f, int lane) {
+  if (lane == 0) atomicAdd(f, 1u);
+}
+
 template <bool GEO3D>
 __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
   constexpr int MAXT = 4, MAXPX = 10, MAXPY = 4;
@@ -916,6 +931,10 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
   const int XB = px << 10, YB = py << 10;
   typedef __attribute__((address_space(3))) char lds_char;
   const unsigned lds_base = (unsigned)(size_t)(lds_char*)lds;
+  unsigned* const fl_ready = (unsigned*)(lds + w.nbuf * (XB + YB));  // [4] tiles landed per slot (x 4 loader waves), [4] freed (x 8 compute waves)
+  unsigned* const fl_freed = fl_ready + 4;
+  const bool flags = w.flags != 0;
+  if (flags && threadIdx.x < 8) fl_ready[threadIdx.x] = 0u;  // (ordered before any use by the prologue barrier)
   int pair, split;
   if (w.nsplit >= 8) {  // XCD-aware placement: see k_conv_wgrad
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -975,6 +994,8 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     if (NB == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // prologue: tile 0 has landed
+    if (flags) flag_bump(fl_ready + 0, lane);
+    int it = 0;  // index of the current tile in this workgroup's sequence
     [[maybe_unused]] unsigned long long lseg[3] = {0, 0, 0}, lt0 = 0;
 #ifdef MI_WG2_DIAG_BAR
     lt0 = __builtin_amdgcn_s_memtime();
@@ -982,13 +1003,19 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     while (true) {
       const int next = tile + tstep;
       const int free_slot = slot == 0 ? NB - 1 : slot - 1;  // released by the barrier that ended the previous iteration
+      if (flags && it > 0) {  // free_slot held tile it-1, its ((it-1)/NB + 1)-th tenant: all eight compute waves must have left it
+        WG2_T0(); flag_wait(fl_freed + free_slot, 8u * (unsigned)((it - 1) / NB + 1)); WG2_T1(lseg[2]);
+      }
       { WG2_T0(); request(tile + (NB - 1) * tstep, free_slot); WG2_T1(lseg[0]); }
-      { WG2_T0(); wait_next(); WG2_T1(lseg[1]); }
-      { WG2_T0(); __builtin_amdgcn_s_barrier(); WG2_T1(lseg[2]); }
+      { WG2_T0(); wait_next(); WG2_T1(lseg[1]); }  // tile it+1 has landed
+      if (flags) flag_bump(fl_ready + (slot + 1 == NB ? 0 : slot + 1), lane);
+      else { WG2_T0(); __builtin_amdgcn_s_barrier(); WG2_T1(lseg[2]); }
       if (next >= tend) break;
       tile = next;
       slot = slot + 1 == NB ? 0 : slot + 1;
+      ++it;
     }
+    if (flags) __builtin_amdgcn_s_barrier();  // every compute wave has finished its last tile (the images are dead after this)
 #ifdef MI_WG2_DIAG_BAR
     if (blockIdx.x == 0 && wave == 8 && lane == 0) {
       g_wg2_clk[0] = __builtin_amdgcn_s_memtime() - lt0;
@@ -1053,8 +1080,10 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
 #ifdef MI_WG2_DIAG_BAR
   ct0 = __builtin_amdgcn_s_memtime();
 #endif
+  int it = 0;
   while (true) {
     ++ntl;
+    if (flags) { WG2_T0(); flag_wait(fl_ready + buf, 4u * (unsigned)(it / NB + 1)); WG2_T1(cbar); }
     if (cs_wave && n != cs_n) {
       cs_flush(cs_n);
       cs_n = n;
@@ -1088,17 +1117,24 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
         }
       }
     }
-    { WG2_T0(); __builtin_amdgcn_s_barrier(); WG2_T1(cbar); }  // this tile's buffers are free; the next tile's images have landed
+    if (flags) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the tile have returned
+      flag_bump(fl_freed + buf, lane);
+    } else {
+      WG2_T0(); __builtin_amdgcn_s_barrier(); WG2_T1(cbar);  // this tile's buffers are free; the next tile's images have landed
+    }
     const int next = tile + tstep;
     if (next >= tend) break;
     tile = next;
     buf = buf + 1 == NB ? 0 : buf + 1;
+    ++it;
     walk_step(walk, g);
     walk_origin(walk, g, n, d0, h0, w0);
   }
 #ifdef MI_WG2_DIAG_BAR
   if (blockIdx.x == 0 && wave == 0 && lane == 0) { g_wg2_clk[4] = __builtin_amdgcn_s_memtime() - ct0; g_wg2_clk[5] = cbar; g_wg2_clk[6] = ntl; g_wg2_clk[7] = nt; }
 #endif
+  if (flags) __builtin_amdgcn_s_barrier();  // (pairs with the loaders': the images are dead, the k-split fold may reuse them)
   if (cs_wave) cs_flush(cs_n);
 
   float* out = w.part + (int64_t)split * w.split_stride + w.pair_off[pair];
@@ -1989,7 +2025,9 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
         py <= 16 && dyb < (1ll << 32)) {
       w.dy_bytes = (unsigned)dyb;
       w.nbuf = (P->KT == 1 && px == 16 && py == 16) ? 4 : 2;  // 1x1: tiles are pure loads -> three tiles in flight per workgroup
-      const size_t lds2 = (size_t)(w.nbuf * (px + py)) * 1024;
+      static const int use_flags = env_int("MI_WGRAD_FLAGS", 1);
+      w.flags = use_flags;
+      const size_t lds2 = (size_t)(w.nbuf * (px + py)) * 1024 + 64;  // + the hand-off counters
       const bool geo3 = P->full27 && a.g.row == WG3_XROW && a.g.slice == WG3_XSLICE && a.g.TD == 4 && a.g.TH == 8 && a.g.TW == 8;
       static bool attr3 = false, attrg = false;
       bool& done = geo3 ? attr3 : attrg;
