@@ -181,7 +181,7 @@ class _ArenaTrainer:
         inside a capture: the all-reduces are issued between the replays, the early segment's concurrently with the second graph."""
         if self.grad_accumulate_step != 1:
             raise RuntimeError("hipGraph capture covers grad_accumulate_step == 1; use step() for accumulation")
-        self._static = tuple(t.clone() for t in inputs)
+        self._static = tuple(None if t is None else t.clone() for t in inputs)  # (None: an optional input that is not used)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -222,6 +222,8 @@ class _ArenaTrainer:
             raise RuntimeError("the model's parameter arena was rebuilt after capture(): create a new trainer (or call capture() again)")
         for buf, t in zip(self._static, inputs):
             if t is not None:
+                if buf is None:
+                    raise ValueError("this input was None at capture(): capture again with a tensor in its place")
                 buf.copy_(t)
         ex = self._exchange() if self.world > 1 else None
         self._g_fb.replay()
@@ -236,7 +238,9 @@ class _ArenaTrainer:
 
 
 class DDPMTrainer(_ArenaTrainer):
-    """step(x0, noise, timesteps[, class_labels]): x0/noise fp32 NCDHW, timesteps (and class_labels) int64 [N]."""
+    """step(x0, noise, timesteps[, class_labels][, context=...]): x0/noise fp32 NCDHW, timesteps (and class_labels) int64 [N];
+    context: fp32 [N, tokens, cross_attention_dim] for a net built with with_conditioning=True (the `context=` of
+    DiffusionModelUNet.forward, UNet:1936-1944), a constant of the step like in forward()."""
 
     def __init__(self, model, lr=2e-5, optimizer="AdamW", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  schedule: DDPMSchedule | None = None, process_group=None, bucket_mb=64, device=None, grad_accumulate_step=1):
@@ -244,9 +248,9 @@ class DDPMTrainer(_ArenaTrainer):
                          grad_accumulate_step)
         self.schedule = schedule or DDPMSchedule(device=self.device)
 
-    def _forward(self, x0, noise, timesteps, class_labels=None):
+    def _forward(self, x0, noise, timesteps, class_labels=None, context=None):
         """q-sample -> UNet -> MSE (+ its gradient).  x0/noise: fp32 NCDHW, timesteps: int64 [N]; class_labels: int64 [N], only for
-        a net built with num_class_embeds."""
+        a net built with num_class_embeds; context: fp32 [N, tokens, cross_attention_dim], only for with_conditioning=True."""
         m = self.model
         a = self.arena
         # raw pointers go to the kernels: refuse anything they would misread instead of reading out of bounds
@@ -274,10 +278,17 @@ class DDPMTrainer(_ArenaTrainer):
         ctx = E.Ctx(a, m._plans, grad_enabled=True, prepacked=m.pack_all())
         if (class_labels is None) != (getattr(m, "num_class_embeds", None) is None):
             raise ValueError("class_labels should be provided exactly when the model has num_class_embeds")
-        pred = m._run(ctx, x_t, timesteps, need_dx=False, class_labels=class_labels)
+        ctx_tokens = None
+        if (context is not None) != bool(getattr(m, "with_conditioning", False)):
+            raise ValueError("context should be provided exactly when the model has with_conditioning = True")
+        if context is not None:
+            if not context.is_cuda or context.dtype != F32 or context.dim() != 3 or context.shape[0] != n or context.shape[2] != m.cross_attention_dim:
+                raise ValueError(f"context must be a GPU fp32 tensor [batch, tokens, {m.cross_attention_dim}]")
+            ctx_tokens = ops.cast_bf16(context.contiguous().reshape(-1, context.shape[2]))
+        pred = m._run(ctx, x_t, timesteps, need_dx=False, class_labels=class_labels, context=ctx_tokens)
         dpred = torch.empty_like(pred)
         call("mi_mse_fwd_bwd", ptr(pred), ptr(target), ptr(dpred), ptr(self.loss), n, pred.shape[-1], v, 1.0)
-        self._keep = (x_t, target)  # read by kernels still in flight / by the second graph of a split capture
+        self._keep = (x_t, target, ctx_tokens)  # read by kernels still in flight / by the second graph of a split capture
         return ctx.tape, pred, dpred
 
 

@@ -182,6 +182,38 @@ def test_ae_extra_loss_hook_matches_oracle():
     assert cos >= 0.9 and abs(ratio - 1) <= 0.1
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_conditioned_step_matches_oracle(graph):
+    """DDPMTrainer(..., context=...): the fused step of a with_conditioning=True net (cross-attention on a context, UNet:72-342,
+    1936-1944) against the oracle's q-sample -> UNet(context) -> MSE -> backward; the context is a constant of the step."""
+    from medical_image_generation_amd.trainer import DDPMTrainer
+    c, ref, net = _nets("unet2d_xattn")
+    tr = DDPMTrainer(net, lr=cases.STEP_LR, optimizer="AdamW", max_grad_norm=1.0)
+    sched = step.DDPMSchedule()
+    x0 = synth.ellipsoid_volume(S, "x0", c["shape"])
+    noise = synth.tensor(S, "noise0", c["shape"])
+    t = torch.tensor(c["timesteps"])
+    context = synth.tensor(S, "context", c["context"])
+    noisy = sched.add_noise(x0, noise, t)
+    pred = ref(noisy, t, context=context)
+    loss_ref = torch.nn.functional.mse_loss(pred.float(), noise.float())
+    loss_ref.backward()
+    args = (x0.cuda(), noise.cuda(), t.cuda(), None, context.cuda())
+    if graph:
+        tr.capture(*args)
+        tr._g_fb.replay()
+    else:
+        tr.forward_backward(*args)
+    names = [n for n, p in ref.named_parameters() if p.grad is not None]
+    g_ref = torch.cat([dict(ref.named_parameters())[n].grad.flatten() for n in names])
+    g_hip = torch.cat([tr.arena.gview(n).cpu().flatten() for n in names])
+    e = float((g_hip - g_ref).norm() / g_ref.norm())
+    print(f"\n[conditioned step graph={graph}] loss {float(tr.loss):.6f} vs {float(loss_ref):.6f}; gradient rel-L2 {e:.3e}")
+    assert abs(float(tr.loss) - float(loss_ref)) <= 1e-2 * float(loss_ref) and e <= 4e-2
+    with pytest.raises(ValueError):
+        tr.forward_backward(x0.cuda(), noise.cuda(), t.cuda())  # a conditioned net needs its context
+
+
 def test_v_prediction_step_matches_oracle():
     """prediction_type = "v_prediction" (train_ldm.py:163-165): the target is scheduler.get_velocity(x0, noise, t)."""
     from medical_image_generation_amd.trainer import DDPMSchedule, DDPMTrainer
