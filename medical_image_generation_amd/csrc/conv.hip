@@ -1702,7 +1702,22 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   P->wg_split_stride = off;
   P->wg_nitems = (int)(off / 1024);
   int ntiles = N * P->g_wg.tilesD * P->g_wg.tilesH * P->g_wg.tilesW;
-  int nsplit = (256 + npairs - 1) / npairs;            // one workgroup per CU (the kernel runs one wave per SIMD)
+  // One workgroup per CU (112 KB of LDS each), and workgroup i of a launch goes to XCD i % 8: an XCD that is dealt more than its 32
+  // CUs' worth runs a second round.  Rounding 256 / npairs UP (what this did) deals 33 workgroups to five XCDs for 3 pairs (96 -> 32),
+  // and the launch takes twice as long: 554 us where 32 -> 32, a third of the work, takes 123.  Cost of a split = rounds x (tiles per
+  // workgroup + 6: prologue, accumulator flush and the slab it adds to the reduce, in tile times -- three rounds of 32 tiles measured
+  // 383 us against ~305 for one round of 103); ties go to the coarser split.
+  int nsplit = 1;
+  {
+    int64_t best = -1;
+    for (int ns = 1; ns <= 256 && ns <= ntiles; ++ns) {
+      const int per_xcd = ns >= 8 ? npairs * ((ns + 7) / 8) : (npairs * ns + 7) / 8;  // (k_conv_wgrad[2]: XCD-aware placement from 8 splits on)
+      const int64_t rounds = (per_xcd + 31) / 32, cost = rounds * ((ntiles + ns - 1) / ns + 6);
+      if (best < 0 || cost < best) { best = cost; nsplit = ns; }
+    }
+  }
+  static const int old_split = env_int("MI_WGRAD_SPLIT_OLD", 0);  // A/B knob: the round-1 choice
+  if (old_split) nsplit = (256 + npairs - 1) / npairs;
   if (nsplit > ntiles) nsplit = ntiles;
   while (nsplit > 1 && (int64_t)nsplit * off * 4 > (256ll << 20)) nsplit /= 2;  // cap the slab at 256 MiB
   if (nsplit < 1) nsplit = 1;
