@@ -79,7 +79,9 @@ def test_elementwise_family(ops):
 
 
 @pytest.mark.parametrize("shape,groups", [((2, 32, 4, 6, 5), 32), ((1, 96, 8, 8, 8), 32), ((2, 64, 1, 16, 16), 16),
-                                          ((1, 16, 5, 5, 5), 8), ((1, 512, 4, 4, 4), 32)])
+                                          ((1, 16, 5, 5, 5), 8), ((1, 512, 4, 4, 4), 32),
+                                          # coarse-level shapes (8 / 16 channels per group, few voxels)
+                                          ((2, 256, 5, 6, 7), 32), ((1, 256, 16, 16, 16), 32), ((1, 512, 16, 16, 16), 32)])
 @pytest.mark.parametrize("silu", [True, False])
 def test_groupnorm_fwd_bwd(ops, shape, groups, silu):
     x = rnd(*shape, scale=1.5) + 0.3
@@ -98,9 +100,9 @@ def test_groupnorm_fwd_bwd(ops, shape, groups, silu):
     st = ops.gn_stats(xc, groups, eps, gamma.to(dev), beta.to(dev))
     check(cf(ops.gn_apply(xc, st, silu)), y.detach(), 1e-2, "gn fwd")
     dgamma, dbeta = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
-    other = rnd(*shape, seed=8)
-    dx = ops.gn_bwd(cl(g), xc, st, gamma.to(dev), silu, dgamma, dbeta, add=cl(other))
-    check(cf(dx), xr.grad + other, 1.5e-2, "gn dx")
+    other, other2 = rnd(*shape, seed=8), rnd(*shape, seed=9)
+    dx = ops.gn_bwd(cl(g), xc, st, gamma.to(dev), silu, dgamma, dbeta, add=cl(other), add2=cl(other2))
+    check(cf(dx), xr.grad + other + other2, 1.5e-2, "gn dx")
     check(dgamma.cpu(), gr.grad, 1e-2, "gn dgamma")
     check(dbeta.cpu(), br.grad, 1e-2, "gn dbeta")
 
