@@ -264,6 +264,9 @@ __device__ __forceinline__ void taps(CState<NCB>& s, int lane) {
     constexpr int cur = (T + PAR) & 1;
     if constexpr (T % KK::GT == 0) compute_top<T / KK::GT, NCB>(s, lane);
     if constexpr (T + 1 < 27) {
+#ifdef MI_C27_DIAG_TAPS8  // timing probe: what would an 8-tap (phase) convolution cost in this kernel's structure?  (taps 8..25 skipped)
+      if constexpr (T < 8)
+#endif
       tap_body<T + 1, NCB, FLIP>(s.acc, s.fr[cur], s.fr[cur ^ 1], s.bcur, (T + 1) % KK::GT == 0 ? s.abase_next : s.abase);
     } else {  // next: first tap of the next image -- other halo buffer, next group's slot
       const unsigned delta = s.cur ? 0u - (unsigned)HALO_BYTES : (unsigned)HALO_BYTES;
