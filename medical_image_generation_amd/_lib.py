@@ -72,8 +72,8 @@ _SIGS = {
     "mi_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_crop_pad": [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p],
-    "mi_qsample": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
-    "mi_ddpm_step": [_p, _p, _p, _p, _p, _p, _i, _i, _l, _i, _p],
+    "mi_qsample": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _l, _i, _p],
+    "mi_ddpm_step": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _i, _p],
     "mi_mse_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _f, _p],
     "mi_l1_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _i, _p],
     "mi_reparam_kl_fwd": [_p, _p, _p, _p, _p, _i, _i, _l, _f, _p],
@@ -88,6 +88,10 @@ _RET = {"mi_gn_workspace_bytes": _l, "mi_attn_workspace_bytes": _l}
 _NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes", "mi_attn_supported", "mi_attn_workspace_bytes", "mi_conv_fwd_stats_chunks"}
 
 _lib = None
+# Version of the C ABI this binding was written against (csrc/api.hip: mi_abi_version).  Entry points have changed their argument
+# lists under unchanged names between versions, and *.so files are not tracked by git: a stale library (or an MI_LIB_PATH pointing at
+# an old ablation build) resolves every symbol and then reads shifted arguments.  load() refuses it.
+ABI_VERSION = 4
 
 
 def exported_symbols() -> list[str]:
@@ -103,6 +107,14 @@ def load():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU / PyTorch fallback for the HIP path)")
         lib = C.CDLL(LIB_PATH)
+        try:
+            lib.mi_abi_version.restype = _i
+            have = int(lib.mi_abi_version())
+        except AttributeError:
+            have = None
+        if have != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} is a stale library (C ABI {have}, this binding needs {ABI_VERSION}): rebuild it with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'`")
         for name, args in _SIGS.items():
             fn = getattr(lib, name)  # AttributeError here = header/library mismatch
             fn.argtypes = args

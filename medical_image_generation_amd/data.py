@@ -103,61 +103,84 @@ class PatchSampler:
             return np.random.uniform() < self.oversample_foreground_percent
         return batch_idx >= round(self.batch_size * (1 - self.oversample_foreground_percent))  # DATA:426-428
 
+    # ---- box placement, one axis at a time.  What the reference's loader does (MedicalDataset.get_bbox, DATA:473-528), stated as
+    # three per-axis rules; the draws on numpy's global generator come in the reference's order (one uniform integer per axis, then --
+    # foreground only -- a class and a voxel, then one jitter per in-plane axis that has room) so a seeded run cuts the same boxes.
+    def _span(self, axis, extent):
+        """[first, last] admissible lower corner along `axis` of a volume of `extent` voxels.  The box may overhang by the slack the
+        (initial) patch has over the final one, split low/high with the odd voxel high; a volume shorter than the box gets exactly
+        the overhang that centres it."""
+        box = self.initial_patch_size[axis]
+        slack = max(int(self.need_to_pad[axis]), box - extent)
+        return -slack // 2, extent + slack // 2 + slack % 2 - box
+
+    def _towards(self, axis, extent, voxel_coord):
+        """Lower corner that centres the box on a foreground voxel, kept inside _span."""
+        first, last = self._span(axis, extent)
+        return max(first, min(int(voxel_coord) - self.initial_patch_size[axis] // 2, last))
+
+    def _in_plane(self, axis, extent):
+        """H / W: the box sits on the volume's centre, shifted by a uniform jitter of at most 10 voxels (less when the margin on
+        either side is smaller; none -- and no draw -- when there is no margin or the volume is narrower than the box)."""
+        box, mid = self.initial_patch_size[axis], extent // 2
+        if extent >= box:
+            room = min(10, mid - box // 2, extent - mid - (box - box // 2))
+            if room > 0:
+                mid += np.random.randint(-room, room + 1)
+        return mid - box // 2
+
     def get_bbox(self, data_shape, force_fg, class_locations):
-        """DATA:473-528: random / foreground-centred along the slice axis, centre crop with <= 10 voxels of jitter in H and W."""
-        dim = len(data_shape)
-        need_to_pad = self.need_to_pad.copy()
-        for d in range(dim):
-            if need_to_pad[d] + data_shape[d] < self.initial_patch_size[d]:
-                need_to_pad[d] = self.initial_patch_size[d] - data_shape[d]
-        lbs = [-need_to_pad[i] // 2 for i in range(dim)]
-        ubs = [data_shape[i] + need_to_pad[i] // 2 + need_to_pad[i] % 2 - self.initial_patch_size[i] for i in range(dim)]
-        bbox_lbs = [np.random.randint(lbs[i], ubs[i] + 1) for i in range(dim)]
-        if force_fg and class_locations is not None:
-            eligible = [cls for cls in class_locations if len(class_locations[cls]) > 0]
-            if eligible:
-                voxels = class_locations[np.random.choice(eligible)]
-                voxel = voxels[np.random.choice(len(voxels))]
-                for i in range(dim):
-                    if self.is_2d and i == 0:
-                        bbox_lbs[0] = voxel[0]
-                    elif not self.is_2d:
-                        bbox_lbs[i] = max(lbs[i], min(voxel[i] - self.initial_patch_size[i] // 2, ubs[i]))
-        for i in range(dim - 2, dim):
-            crop, size = self.initial_patch_size[i], data_shape[i]
-            center = size // 2
-            if size < crop:
-                bbox_lbs[i] = center - crop // 2
+        """(lower corners, upper corners) of the next patch in a volume of spatial shape `data_shape` (DATA:473-528)."""
+        axes = range(len(data_shape))
+        lower = []
+        for ax in axes:  # every axis draws, also those overwritten below: the generator's state must advance as the reference's does
+            first, last = self._span(ax, data_shape[ax])
+            lower.append(np.random.randint(first, last + 1))
+        classes = [c for c in class_locations if len(class_locations[c]) > 0] if (force_fg and class_locations is not None) else []
+        if classes:
+            voxels = class_locations[np.random.choice(classes)]
+            voxel = voxels[np.random.choice(len(voxels))]
+            if self.is_2d:
+                lower[0] = voxel[0]  # pseudo 3-D: the slice that holds the voxel
             else:
-                max_offset = min(10, center - crop // 2, size - center - (crop - crop // 2))
-                offset = np.random.randint(-max_offset, max_offset + 1) if max_offset > 0 else 0
-                bbox_lbs[i] = center + offset - crop // 2
-        return bbox_lbs, [bbox_lbs[i] + self.initial_patch_size[i] for i in range(dim)]
+                lower = [self._towards(ax, data_shape[ax], voxel[ax]) for ax in axes]
+        for ax in list(axes)[-2:]:
+            lower[ax] = self._in_plane(ax, data_shape[ax])
+        return lower, [lo + self.initial_patch_size[ax] for ax, lo in zip(axes, lower)]
 
 
 class BatchOrder:
-    """CustomBatchSampler (DATA:601-643): a fixed number of steps per epoch; every sample is used once before any is repeated."""
+    """The epoch schedule of the reference's CustomBatchSampler (DATA:601-643): `number_of_steps` batches per epoch; within an epoch
+    every sample is dealt once before any is dealt again (a new shuffled deck whenever fewer than a batch of cards is left).  The deck
+    is a member and is shuffled IN PLACE at the start of every epoch, so epoch k starts from epoch k-1's permutation like the
+    reference's `self.indices` does (a deck rebuilt from range(n) each epoch would draw other batches from epoch 2 on)."""
 
     def __init__(self, n_items, batch_size, number_of_steps=250, shuffle=True):
         self.n_items, self.batch_size, self.number_of_steps, self.shuffle = n_items, batch_size, number_of_steps, shuffle
+        self.indices = list(range(n_items))
 
     def __len__(self):
         return self.number_of_steps
 
-    def __iter__(self):
-        indices = list(range(self.n_items))
+    def _deal(self):
+        """Sample indices of one epoch as one flat run, `number_of_steps * batch_size` long."""
         if self.shuffle:
-            np.random.shuffle(indices)
-        order, available = [], indices.copy()
-        while len(order) < self.number_of_steps * self.batch_size:
-            if len(available) < self.batch_size:
-                available = indices.copy()
+            np.random.shuffle(self.indices)
+        want = self.number_of_steps * self.batch_size
+        deck, run = list(self.indices), []
+        while len(run) < want:
+            if len(deck) < self.batch_size:  # fewer cards than a batch: the leftovers go away with the old deck
+                deck = list(self.indices)
                 if self.shuffle:
-                    np.random.shuffle(available)
-            order.extend(available[:self.batch_size])
-            available = available[self.batch_size:]
+                    np.random.shuffle(deck)
+            run += deck[:self.batch_size]
+            del deck[:self.batch_size]
+        return run
+
+    def __iter__(self):
+        run, b = self._deal(), self.batch_size
         for k in range(self.number_of_steps):
-            yield [(i, s) for i, s in enumerate(order[k * self.batch_size:(k + 1) * self.batch_size])]
+            yield list(enumerate(run[k * b:(k + 1) * b]))
 
 
 class GpuPatchLoader:
@@ -172,6 +195,7 @@ class GpuPatchLoader:
         self.sampler = PatchSampler(patch_size, batch_size, oversample_foreground_percent)
         self.order = BatchOrder(len(dataset), batch_size, number_of_steps, shuffle=section == "training")
         self.mirror, self.brightness_range, self.channel_ids, self.transform = mirror, brightness_range, channel_ids, transform
+        self._selected = {}  # id -> the channel-selected copy of its resident volume (made once, not per sample)
 
     def __len__(self):
         return len(self.order)
@@ -194,10 +218,14 @@ class GpuPatchLoader:
                         flip = 4  # W axis: mirror_axes = (2,) in 3-D / (1,) in 2-D (DATA:410)
                     if self.brightness_range is not None and np.random.uniform() < 0.15:
                         scale = float(np.random.uniform(*self.brightness_range))
-                src = vol4 if self.channel_ids is None else vol4[self.channel_ids].contiguous()
+                src = vol4
+                if self.channel_ids is not None:
+                    src = self._selected.get(name)
+                    if src is None:
+                        src = self._selected[name] = vol4[list(self.channel_ids)].contiguous()
                 crop_and_pad_nd(src, [[a, b] for a, b in zip(lbs, ubs)], 0, flip_mask=flip, scale=scale, clamp01=True, out=out[batch_idx])
                 names.append(name)
             image = out.squeeze(2) if s.is_2d else out
-            if self.transform is not None:
-                image = self.transform(image)
+            if self.transform is not None:  # the reference clamps AFTER its transform list (DATA:590-595)
+                image = self.transform(image).clamp_(0, 1)
             yield {"id": names, "image": image}

@@ -30,9 +30,12 @@ def _world(group=None):
     return dist.get_world_size(group) if dist.is_initialized() else 1
 
 
-def sum_gradients(flat_grad: torch.Tensor, lo: int, hi: int, group=None, bucket_elems: int = 16 << 20, async_op: bool = False):
-    """In-place SUM over ranks of flat_grad[lo:hi].  Returns the work handles when async_op (else [])."""
-    if _world(group) <= 1 or hi <= lo:
+def sum_gradients(flat_grad: torch.Tensor, lo: int, hi: int, group=None, bucket_elems: int = 16 << 20, async_op: bool = False,
+                  force: bool = False):
+    """In-place SUM over ranks of flat_grad[lo:hi].  Returns the work handles when async_op (else []).  force: issue the collectives
+    even in a one-rank group (a sum over one rank changes nothing, but the collective library's launch, stream and event path runs:
+    how the RCCL calls between the hipGraph replays are rehearsed on a single GPU, tests/test_trainer_gpu.py)."""
+    if hi <= lo or (_world(group) <= 1 and not (force and dist.is_initialized())):
         return []
     works = []
     for a, b in bucket_slices(hi - lo, bucket_elems, lo):
@@ -57,21 +60,22 @@ class GradientExchange:
     finish() returns once every all-reduce has been waited for (for NCCL/RCCL `wait` only makes the current stream wait: the host
     does not block).  With world 1 both calls are no-ops."""
 
-    def __init__(self, flat_grad: torch.Tensor, n_late: int, n_trainable: int, group=None, bucket_elems: int = 16 << 20):
+    def __init__(self, flat_grad: torch.Tensor, n_late: int, n_trainable: int, group=None, bucket_elems: int = 16 << 20, force: bool = False):
         if not 0 <= n_late <= n_trainable <= flat_grad.numel():
             raise ValueError("need 0 <= n_late <= n_trainable <= numel")
         self.grad, self.n_late, self.n_trainable, self.group, self.bucket = flat_grad, n_late, n_trainable, group, bucket_elems
+        self.force = force
         self.works = []
         self.early_started = False
 
     def start_early(self):
         assert not self.early_started
         self.early_started = True
-        self.works += sum_gradients(self.grad, self.n_late, self.n_trainable, self.group, self.bucket, async_op=True)
+        self.works += sum_gradients(self.grad, self.n_late, self.n_trainable, self.group, self.bucket, async_op=True, force=self.force)
 
     def finish(self):
         lo_hi = (0, self.n_late) if self.early_started else (0, self.n_trainable)
-        self.works += sum_gradients(self.grad, lo_hi[0], lo_hi[1], self.group, self.bucket, async_op=True)
+        self.works += sum_gradients(self.grad, lo_hi[0], lo_hi[1], self.group, self.bucket, async_op=True, force=self.force)
         for w in self.works:
             w.wait()
         self.works, self.early_started = [], False

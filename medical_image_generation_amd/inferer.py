@@ -90,7 +90,9 @@ class DDPMScheduler:
 class _Loop:
     """One captured denoising step, replayed over scheduler.timesteps."""
 
-    def __init__(self, model, scheduler, shape, device):
+    def __init__(self, model, scheduler, shape, device, cond_channels=0, context_shape=None):
+        """cond_channels: channels of a mode="concat" conditioning tensor that sit, un-noised, behind the sample's channels in the model
+        input; context_shape: (tokens, cross_attention_dim) of a mode="crossattn" conditioning."""
         self.m, self.sch = model, scheduler
         n, c = shape[0], shape[1]
         sp = tuple(shape[2:])
@@ -100,7 +102,9 @@ class _Loop:
         dims = (1,) * (3 - len(sp)) + sp
         self.n, self.c = n, c
         self.x = torch.empty(shape, dtype=F32, device=device)                    # the sample, fp32 NC[D]HW
-        self.x_cl = torch.empty((n,) + dims + (c,), dtype=torch.bfloat16, device=device)  # ... as the model reads it
+        self.cc = int(cond_channels)
+        self.x_cl = torch.empty((n,) + dims + (c + self.cc,), dtype=torch.bfloat16, device=device)  # ... as the model reads it (+ condition)
+        self.ctx = None if context_shape is None else torch.empty((n * context_shape[0], context_shape[1]), dtype=torch.bfloat16, device=device)
         self.z = torch.empty(shape, dtype=F32, device=device)
         self.t = torch.zeros(1, dtype=torch.int64, device=device)
         self.tn = torch.zeros(n, dtype=torch.int64, device=device)
@@ -112,15 +116,23 @@ class _Loop:
 
     def _step(self):
         ctx = E.Ctx(self.arena, self.m._plans, grad_enabled=False, prepacked=self.keys)
-        eps = self.m._run(ctx, self.x_cl, self.tn, need_dx=False)
-        call("mi_ddpm_step", ptr(self.x), ptr(eps), ptr(self.z), ptr(self.coef), ptr(self.t), ptr(self.x_cl), self.n, self.c, self.v,
-             int(self.sch.clip_sample) | (2 if self.sch.prediction_type == "v_prediction" else 0))
+        eps = self.m._run(ctx, self.x_cl, self.tn, need_dx=False, context=self.ctx)
+        call("mi_ddpm_step", ptr(self.x), ptr(eps), ptr(self.z), ptr(self.coef), ptr(self.t), ptr(self.x_cl), self.c + self.cc, self.n, self.c,
+             self.v, int(self.sch.clip_sample) | (2 if self.sch.prediction_type == "v_prediction" else 0))
 
-    def run(self, input_noise, noises=None, generator=None, use_graph=True, on_step=None):
+    def _load(self, x):
+        """x (fp32 NC[D]HW) -> the sample channels of the model input (the condition channels behind them stay)."""
+        self.x.copy_(x)
+        self.x_cl[..., :self.c].copy_(ops.to_channels_last(self.x))
+
+    def run(self, input_noise, noises=None, generator=None, use_graph=True, on_step=None, conditioning=None):
         if self.m._arena is not self.arena:  # the module moved (.to / .cuda): plans and graph point at the old buffers -> start over
             self.arena, self.graph, self.keys, self._pinned = self.m.arena(self.x.device), None, (), None
-        self.x.copy_(input_noise)
-        self.x_cl.copy_(ops.to_channels_last(self.x))
+        if self.cc:  # mode="concat": model_input = cat([image, conditioning], dim=1) at every step; written once, the steps rewrite `image`
+            self.x_cl[..., self.c:].copy_(ops.to_channels_last(conditioning))
+        elif self.ctx is not None:  # mode="crossattn": the context token matrix is a constant of the loop
+            self.ctx.copy_(ops.cast_bf16(conditioning.contiguous().reshape(-1, conditioning.shape[2])))
+        self._load(input_noise)
         steps = [int(t) for t in self.sch.timesteps]
         keep = self.x.clone()
         if not self.m._plans or len(self.keys) != len(self.m._plans):
@@ -140,8 +152,7 @@ class _Loop:
             with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self._step()
             self._pinned = (dict(self.m._plans), dict(ops._ws_cache), self.arena)  # keep what the graph points at alive
-        self.x.copy_(keep)
-        self.x_cl.copy_(ops.to_channels_last(self.x))
+        self._load(keep)
         for i, t in enumerate(steps):
             self.t.fill_(t)
             self.tn.fill_(t)
@@ -165,30 +176,57 @@ class DiffusionInferer:
         self.scheduler = scheduler
         self._loops = {}
 
-    def _loop(self, model, scheduler, shape, device):
-        key = (id(model), id(scheduler), tuple(shape))
+    def _loop(self, model, scheduler, shape, device, cond_channels=0, context_shape=None):
+        key = (id(model), id(scheduler), tuple(shape), cond_channels, context_shape)
         if key not in self._loops:
-            self._loops[key] = _Loop(model, scheduler, tuple(shape), device)
+            self._loops[key] = _Loop(model, scheduler, tuple(shape), device, cond_channels, context_shape)
         return self._loops[key]
+
+    @staticmethod
+    def _check_mode(mode):
+        if mode not in ("crossattn", "concat"):
+            raise NotImplementedError(f"{mode} condition is not supported")
 
     def __call__(self, inputs, diffusion_model, noise, timesteps, condition=None, mode="crossattn"):
         """The training-side call of train_ddpm.py:191: `noise_pred = inferer(inputs=images, diffusion_model=model, noise=noise,
         timesteps=timesteps)` = diffusion_model(scheduler.add_noise(inputs, noise, timesteps), timesteps) (third-party
         `generative.inferers.DiffusionInferer.__call__`).  Differentiable through the model's autograd edge; the fused
         trainer.DDPMTrainer is the fast path for the same computation."""
-        if condition is not None:
-            raise NotImplementedError("conditioning is not on the HIP path (unused by the reference's configs)")
+        self._check_mode(mode)
         noisy = self.scheduler.add_noise(original_samples=inputs, noise=noise, timesteps=timesteps)
-        return diffusion_model(x=noisy, timesteps=timesteps)
+        if mode == "concat" and condition is not None:  # un-noised condition channels behind the noised ones; no cross-attention context
+            noisy, condition = torch.cat([noisy, condition.to(noisy.dtype)], dim=1), None
+        return diffusion_model(x=noisy, timesteps=timesteps, context=condition)
 
     @torch.no_grad()
     def sample(self, input_noise, diffusion_model, scheduler=None, save_intermediates=False, intermediate_steps=100, conditioning=None,
                mode="crossattn", verbose=True, noises=None, generator=None, use_graph=True):
-        """noises: optional sequence with the z of every step (tests pin them); generator: torch generator for the per-step noise."""
-        if conditioning is not None:
-            raise NotImplementedError("conditioning is not on the HIP path (unused by the reference's configs)")
+        """conditioning with mode="concat": fp32 NC'[D]HW, model_input = cat([image, conditioning], dim=1) at every step; with
+        mode="crossattn": fp32 [N, tokens, cross_attention_dim], the model's `context` (train_ldm.py:349-365 passes neither).
+        noises: optional sequence with the z of every step (tests pin them); generator: torch generator for the per-step noise."""
+        self._check_mode(mode)
         if not input_noise.is_cuda:
             raise RuntimeError("medical_image_generation_amd runs on MI355X only: move the inputs to 'cuda'")
+        cc, ctx_shape = 0, None
+        if conditioning is not None:
+            conditioning = conditioning.to(device=input_noise.device, dtype=F32).contiguous()
+            if mode == "concat":
+                if conditioning.dim() != input_noise.dim() or conditioning.shape[0] != input_noise.shape[0] or \
+                        conditioning.shape[2:] != input_noise.shape[2:]:
+                    raise ValueError("mode='concat': conditioning must have the sample's batch and spatial shape")
+                cc = conditioning.shape[1]
+            else:
+                if not getattr(diffusion_model, "with_conditioning", False):
+                    raise ValueError("model should have with_conditioning = True if context is provided")
+                if conditioning.dim() != 3 or conditioning.shape[0] != input_noise.shape[0] or \
+                        conditioning.shape[2] != diffusion_model.cross_attention_dim:
+                    raise ValueError(f"mode='crossattn': conditioning must be [batch, tokens, {diffusion_model.cross_attention_dim}]")
+                ctx_shape = (conditioning.shape[1], conditioning.shape[2])
+        elif getattr(diffusion_model, "with_conditioning", False):
+            raise ValueError("the model was built with_conditioning=True: pass conditioning=[batch, tokens, cross_attention_dim]")
+        if input_noise.shape[1] + cc != diffusion_model.in_channels:
+            raise ValueError(f"Input number of channels ({input_noise.shape[1] + cc}) is not equal to expected number of channels "
+                             f"({diffusion_model.in_channels})")
         scheduler = scheduler or self.scheduler
         inter = []
 
@@ -196,8 +234,8 @@ class DiffusionInferer:
             if save_intermediates and t % intermediate_steps == 0:
                 inter.append(x.clone())
 
-        loop = self._loop(diffusion_model, scheduler, input_noise.shape, input_noise.device)
-        image = loop.run(input_noise.float(), noises=noises, generator=generator, use_graph=use_graph, on_step=on_step)
+        loop = self._loop(diffusion_model, scheduler, input_noise.shape, input_noise.device, cc, ctx_shape)
+        image = loop.run(input_noise.float(), noises=noises, generator=generator, use_graph=use_graph, on_step=on_step, conditioning=conditioning)
         return (image, inter) if save_intermediates else image
 
 

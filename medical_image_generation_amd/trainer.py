@@ -16,6 +16,8 @@ Data parallelism: one process per GPU; the trainable prefix of the f
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -55,10 +57,14 @@ class _ArenaTrainer:
     finest-resolution levels, conv_in and everything the time-embedding backward writes -- form the *late* prefix).  The SUM
     all-reduce of the early segment (>= 95 % of the bytes) is issued asynchronously at the cut and runs over xGMI while the rest of
     the backward (the full-resolution layers: ~1/3 of its time, almost no parameters) computes; the small late segment follows.
-    The mean is never materialised: 1/world is folded into the optimizer kernel (`grad_scale`)."""
+    The mean is never materialised: 1/world is folded into the optimizer kernel (`grad_scale`).
+
+    overlap=False (or MI_DDP_OVERLAP=0) is the plain schedule: ONE backward (one hipGraph), then the all-reduce of the whole
+    trainable prefix, then the optimizer -- the fallback should the overlapped exchange misbehave on a given RCCL / node (the N > 1
+    overlap has been rehearsed with gloo ranks and with one-rank RCCL groups only: DESIGN.md section 6)."""
 
     def __init__(self, model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device,
-                 grad_accumulate_step=1):
+                 grad_accumulate_step=1, overlap=None):
         self.model = model
         self.device = torch.device(device or "cuda")
         self.lr, self.betas, self.eps = lr, betas, eps
@@ -87,6 +93,8 @@ class _ArenaTrainer:
         self._graph = None
         self._static = None
         self._force_split = False  # tests: capture the two-graph form with world 1
+        self._force_exchange = False  # tests: issue the (one-rank) collectives although world == 1
+        self.overlap = (os.environ.get("MI_DDP_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
 
     # ------------------------------------------------------------------ pieces
     def _forward(self, *inputs):
@@ -122,12 +130,16 @@ class _ArenaTrainer:
             on_cut()
         self._fb_finish(state)
 
+    def _exchanging(self):
+        return self.world > 1 or self._force_exchange
+
     def _exchange(self):
-        return ddp.GradientExchange(self.arena.grad, self.arena.n_late, self.arena.n_trainable, self.pg, self.bucket_elems)
+        return ddp.GradientExchange(self.arena.grad, self.arena.n_late, self.arena.n_trainable, self.pg, self.bucket_elems,
+                                    force=self._force_exchange)
 
     def all_reduce_grads(self):
         """SUM all-reduce of the whole trainable gradient prefix, no overlap (the mean is taken by the optimizer's grad_scale)."""
-        if self.world > 1:
+        if self._exchanging():
             self._exchange().finish()
 
     def optimizer_step(self):
@@ -164,9 +176,9 @@ class _ArenaTrainer:
         grad_accumulate_step = k the optimizer runs on every k-th call (or when last_in_epoch, T-LDM:173); the data-parallel
         exchange happens on that boundary micro-step only."""
         boundary = (self._micro + 1) % self.grad_accumulate_step == 0 or last_in_epoch
-        ex = self._exchange() if self.world > 1 and boundary else None
+        ex = self._exchange() if self._exchanging() and boundary else None
         # the early segment may leave at the cut only when no pending micro-step sum has to be folded in first
-        self.forward_backward(*inputs, on_cut=ex.start_early if ex is not None and self._micro == 0 else None)
+        self.forward_backward(*inputs, on_cut=ex.start_early if ex is not None and self._micro == 0 and self.overlap else None)
         self._fold_micro_step(boundary)
         if not boundary:
             return self.loss
@@ -189,7 +201,7 @@ class _ArenaTrainer:
                 self.forward_backward(*self._static)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        split = (self.world > 1 or self._force_split) and 0 < self.arena.n_late < self.arena.n_trainable
+        split = self.overlap and (self.world > 1 or self._force_split) and 0 < self.arena.n_late < self.arena.n_trainable
         # thread_local: a collective library's watchdog thread polling events must not invalidate the capture
         self._g_fb, self._g_fb2 = torch.cuda.CUDAGraph(), None
         if not split:
@@ -225,7 +237,7 @@ class _ArenaTrainer:
                 if buf is None:
                     raise ValueError("this input was None at capture(): capture again with a tensor in its place")
                 buf.copy_(t)
-        ex = self._exchange() if self.world > 1 else None
+        ex = self._exchange() if self._exchanging() else None
         self._g_fb.replay()
         if self._g_fb2 is not None:
             if ex is not None:
@@ -238,19 +250,25 @@ class _ArenaTrainer:
 
 
 class DDPMTrainer(_ArenaTrainer):
-    """step(x0, noise, timesteps[, class_labels][, context=...]): x0/noise fp32 NCDHW, timesteps (and class_labels) int64 [N];
-    context: fp32 [N, tokens, cross_attention_dim] for a net built with with_conditioning=True (the `context=` of
-    DiffusionModelUNet.forward, UNet:1936-1944), a constant of the step like in forward()."""
+    """step(x0, noise, timesteps[, class_labels][, context=...][, condition=...]): x0/noise fp32 NCDHW, timesteps (and class_labels)
+    int64 [N]; context: fp32 [N, tokens, cross_attention_dim] for a net built with with_conditioning=True (the `context=` of
+    DiffusionModelUNet.forward, UNet:1936-1944), a constant of the step like in forward().
+
+    condition: channel-concatenation conditioning (the third-party inferer's `condition=..., mode="concat"`, the arguments of the call at
+    train_ddpm.py:191; BASELINE configs[4] "label-channel conditioning"): fp32 NC'[D]HW, spatially like x0.  Only x0's channels are
+    noised; the condition channels are written un-noised behind them -- model input = cat([noisy, condition], dim=1) with
+    in_channels = C + C' -- and the model predicts x0's C channels (out_channels = C), compared with x0's noise."""
 
     def __init__(self, model, lr=2e-5, optimizer="AdamW", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
-                 schedule: DDPMSchedule | None = None, process_group=None, bucket_mb=64, device=None, grad_accumulate_step=1):
+                 schedule: DDPMSchedule | None = None, process_group=None, bucket_mb=64, device=None, grad_accumulate_step=1, overlap=None):
         super().__init__(model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device,
-                         grad_accumulate_step)
+                         grad_accumulate_step, overlap)
         self.schedule = schedule or DDPMSchedule(device=self.device)
 
-    def _forward(self, x0, noise, timesteps, class_labels=None, context=None):
+    def _forward(self, x0, noise, timesteps, class_labels=None, context=None, condition=None):
         """q-sample -> UNet -> MSE (+ its gradient).  x0/noise: fp32 NCDHW, timesteps: int64 [N]; class_labels: int64 [N], only for
-        a net built with num_class_embeds; context: fp32 [N, tokens, cross_attention_dim], only for with_conditioning=True."""
+        a net built with num_class_embeds; context: fp32 [N, tokens, cross_attention_dim], only for with_conditioning=True;
+        condition: fp32 NC'[D]HW concatenated un-noised behind the noised channels (mode="concat")."""
         m = self.model
         a = self.arena
         # raw pointers go to the kernels: refuse anything they would misread instead of reading out of bounds
@@ -260,8 +278,18 @@ class DDPMTrainer(_ArenaTrainer):
             raise ValueError("x0 and noise must be contiguous fp32 tensors of the same NC[D]HW shape")
         if timesteps.dtype != torch.int64 or timesteps.shape != (x0.shape[0],) or not timesteps.is_contiguous():
             raise ValueError("timesteps must be a contiguous int64 tensor of shape [N]")  # range: clamped to the schedule in k_qsample
-        if x0.shape[1] != m.in_channels:
-            raise ValueError(f"Input number of channels ({x0.shape[1]}) is not equal to expected number of channels ({m.in_channels})")
+        cc = 0
+        if condition is not None:
+            if not condition.is_cuda or condition.dtype != F32 or not condition.is_contiguous() or condition.dim() != x0.dim() or \
+                    condition.shape[0] != x0.shape[0] or condition.shape[2:] != x0.shape[2:]:
+                raise ValueError("condition must be a contiguous fp32 GPU tensor with x0's batch and spatial shape (mode='concat')")
+            cc = condition.shape[1]
+        if x0.shape[1] + cc != m.in_channels:
+            raise ValueError(f"Input number of channels ({x0.shape[1] + cc}) is not equal to expected number of channels ({m.in_channels})")
+        if x0.shape[1] != m.out_channels:  # the MSE compares the prediction with x0's noise channel for channel
+            raise ValueError(f"the model predicts {m.out_channels} channels but the noised input has {x0.shape[1]}: the loss target "
+                             "(the noise / velocity of x0) must have the prediction's channel count; un-noised conditioning channels go in "
+                             "`condition=`")
         a.grad.zero_()
         sd = m.spatial_dims
         n, c = x0.shape[0], x0.shape[1]
@@ -270,11 +298,11 @@ class DDPMTrainer(_ArenaTrainer):
         for s in sp:
             v *= s
         dims = (1,) * (3 - sd) + sp
-        x_t = torch.empty((n,) + dims + (c,), dtype=torch.bfloat16, device=x0.device)
+        x_t = torch.empty((n,) + dims + (c + cc,), dtype=torch.bfloat16, device=x0.device)
         vpred = self.schedule.prediction_type == "v_prediction"  # target = scheduler.get_velocity(x0, noise, t), T-LDM:163-165
         target = torch.empty_like(noise) if vpred else noise
-        call("mi_qsample", ptr(x0), ptr(noise), ptr(self.schedule.sqrt_acp), ptr(self.schedule.sqrt_1macp), ptr(timesteps), ptr(x_t),
-             ptr(target) if vpred else None, n, c, v, self.schedule.num_train_timesteps)
+        call("mi_qsample", ptr(x0), ptr(noise), ptr(self.schedule.sqrt_acp), ptr(self.schedule.sqrt_1macp), ptr(timesteps), ptr(condition), cc,
+             ptr(x_t), ptr(target) if vpred else None, n, c, v, self.schedule.num_train_timesteps)
         ctx = E.Ctx(a, m._plans, grad_enabled=True, prepacked=m.pack_all())
         if (class_labels is None) != (getattr(m, "num_class_embeds", None) is None):
             raise ValueError("class_labels should be provided exactly when the model has num_class_embeds")
@@ -287,8 +315,10 @@ class DDPMTrainer(_ArenaTrainer):
             ctx_tokens = ops.cast_bf16(context.contiguous().reshape(-1, context.shape[2]))
         pred = m._run(ctx, x_t, timesteps, need_dx=False, class_labels=class_labels, context=ctx_tokens)
         dpred = torch.empty_like(pred)
+        if pred.shape[-1] != target.shape[1]:  # k_mse indexes both with ONE channel count
+            raise ValueError(f"prediction has {pred.shape[-1]} channels, the target {target.shape[1]}")
         call("mi_mse_fwd_bwd", ptr(pred), ptr(target), ptr(dpred), ptr(self.loss), n, pred.shape[-1], v, 1.0)
-        self._keep = (x_t, target, ctx_tokens)  # read by kernels still in flight / by the second graph of a split capture
+        self._keep = (x_t, target, ctx_tokens, condition)  # read by kernels still in flight / by the second graph of a split capture
         return ctx.tape, pred, dpred
 
 
@@ -298,7 +328,7 @@ class LDMTrainer(DDPMTrainer):
         latents = autoencoder.encode_stage_2_inputs(images)   (no grad: T-LDM:154-156)  ->  * scale_factor  ->  q-sample -> UNet
         -> MSE -> backward -> clip -> AdamW
 
-    step(images, eps, noise, timesteps): images fp32 NC[D]HW; eps fp32, latent-shaped -- the torch.randn_like of
+    step(images, eps, noise, timesteps[, class_labels][, context=][, condition=]): images fp32 NC[D]HW; eps fp32, latent-shaped -- the torch.randn_like of
     AutoencoderKL.sampling (AEKL:786-787) made an input so that a captured graph sees fresh noise and tests can pin it; noise fp32,
     latent-shaped (T-LDM:159); timesteps int64 [N].  The encoder runs tape-less on the same HIP kernels inside the same hipGraph.
     `scale_factor`: 1 / std of the first batch's latents (T-LDM:110-112) -- `estimate_scale_factor` -- or given."""
@@ -334,12 +364,14 @@ class LDMTrainer(DDPMTrainer):
         self.scale_factor = float(1.0 / torch.std(self._latents(images, eps)))
         return self.scale_factor
 
-    def _forward(self, images, eps, noise, timesteps, class_labels=None):
+    def _forward(self, images, eps, noise, timesteps, class_labels=None, context=None, condition=None):
+        """condition: latent-shaped fp32 tensor (e.g. the label mask resampled to the latent grid) concatenated un-noised behind the
+        scaled latents -- BASELINE configs[4]."""
         if self.scale_factor is None:
             raise RuntimeError("scale_factor is not set: pass it or call estimate_scale_factor(first_batch, eps) (train_ldm.py:110-112)")
         z = self._latents(images, eps)
         call("mi_scale_f32", ptr(z), self.scale_factor, z.numel())  # latents_scaled = latents * inferer.scale_factor (T-LDM:157)
-        return super()._forward(z, noise, timesteps, class_labels)
+        return super()._forward(z, noise, timesteps, class_labels, context, condition)
 
 
 class AETrainer(_ArenaTrainer):
@@ -356,9 +388,9 @@ class AETrainer(_ArenaTrainer):
     (T-AE:371-397), which is plain torch on the caller's side."""
 
     def __init__(self, model, lr=5e-5, optimizer="Adam", weight_decay=None, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
-                 kl_weight=1e-7, process_group=None, bucket_mb=64, device=None, grad_accumulate_step=1, extra_loss=None):
+                 kl_weight=1e-7, process_group=None, bucket_mb=64, device=None, grad_accumulate_step=1, extra_loss=None, overlap=None):
         super().__init__(model, lr, optimizer, weight_decay, betas, eps, max_grad_norm, process_group, bucket_mb, device,
-                         grad_accumulate_step)
+                         grad_accumulate_step, overlap)
         self.kl_weight = float(kl_weight)
         self.extra_loss = extra_loss
         self.reconstruction = None

@@ -82,17 +82,24 @@ def kl_loss(z_mu, z_sigma):
     return torch.sum(kl) / kl.shape[0]
 
 
-def ddpm_loss(model, schedule: DDPMSchedule, x0, noise, timesteps):
-    """q-sample -> model -> MSE (T-LDM:159-169 / T-DDPM:185-192)."""
+def ddpm_loss(model, schedule: DDPMSchedule, x0, noise, timesteps, condition=None):
+    """q-sample -> model -> MSE (T-LDM:159-169 / T-DDPM:185-192).
+
+    condition: the `condition=..., mode="concat"` arguments of the inferer call at T-DDPM:191 (third-party
+    `generative.inferers.DiffusionInferer.__call__`, source absent: restated from upstream -- PARITY UNPINNED):
+    the un-noised condition is concatenated behind the NOISED image on the channel axis, the model predicts
+    the image's channels and the target is the image's noise (BASELINE configs[4])."""
     noisy = schedule.add_noise(x0, noise, timesteps)
+    if condition is not None:
+        noisy = torch.cat([noisy, condition], dim=1)
     pred = model(noisy, timesteps)
     target = schedule.get_velocity(x0, noise, timesteps) if schedule.prediction_type == "v_prediction" else noise
     return F.mse_loss(pred.float(), target.float()), pred
 
 
-def ddpm_train_step(model, optimizer, schedule, x0, noise, timesteps, max_norm: float | None = 1.0):
+def ddpm_train_step(model, optimizer, schedule, x0, noise, timesteps, max_norm: float | None = 1.0, condition=None):
     """backward -> clip_grad_norm_ -> step -> zero_grad (T-LDM:171-180)."""
-    loss, pred = ddpm_loss(model, schedule, x0, noise, timesteps)
+    loss, pred = ddpm_loss(model, schedule, x0, noise, timesteps, condition)
     loss.backward()
     if max_norm:
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm)

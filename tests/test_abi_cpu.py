@@ -15,12 +15,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_every_declared_symbol():
     from medical_image_generation_amd import _lib
     lib = _lib.load()  # raises if the .so is missing
-    assert lib.mi_abi_version() == 3
+    assert lib.mi_abi_version() == _lib.ABI_VERSION
+    api = open(os.path.join(ROOT, "medical_image_generation_amd", "csrc", "api.hip")).read()
+    assert f"return {_lib.ABI_VERSION};" in api  # the binding and the source agree on the version the loader checks
     hdr = open(os.path.join(ROOT, "include", "medimgen_hip.h")).read()
     declared = set(re.findall(r"\b(mi_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.exported_symbols())
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_stale_library_is_refused(tmp_path, monkeypatch):
+    """A library whose mi_abi_version() differs from the binding's (an old build left behind by a pull: *.so is not tracked) must not
+    load -- several entry points changed their argument lists under unchanged names."""
+    import subprocess
+    from medical_image_generation_amd import _lib
+    src = tmp_path / "stale.c"
+    src.write_text(f"int mi_abi_version(void) {{ return {_lib.ABI_VERSION - 1}; }}\n")
+    so = tmp_path / "libstale.so"
+    subprocess.run(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(so))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="stale library"):
+        _lib.load()
 
 
 def test_product_does_not_import_oracle():

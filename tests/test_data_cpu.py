@@ -52,6 +52,82 @@ def test_patch_sampler_draws_the_oracles_boxes(patch, shape):
     assert [ps.force_foreground(i) for i in range(4)] == [od.oversample_last_percent(i, 4, 0.33) for i in range(4)] == [False, False, False, True]
 
 
+class _ScriptedRandint:
+    """np.random.randint replaced by a script: records (low, high) of every call, returns low / high - 1 / the middle as told."""
+
+    def __init__(self, picks):
+        self.picks, self.calls = list(picks), []
+
+    def __call__(self, low, high=None):
+        self.calls.append((int(low), int(high)))
+        how = self.picks.pop(0)
+        return {"lo": low, "hi": high - 1, "mid": (low + high - 1) // 2}[how]
+
+
+def test_patch_sampler_boxes_derived_by_hand(monkeypatch):
+    """Boxes worked out on paper from the rules of MedicalDataset.get_bbox (DATA:473-528), not from another implementation: the
+    generator is scripted, so every draw's RANGE (checked) and the resulting corners (checked) are hand-derived.
+      A. volume 40x100x120, patch 32x64x64: slice axis free in [0, 8]; H: centre 50, margins 18/18 -> jitter +-10; W: centre 60,
+         margins 28/28 -> jitter +-10.  All draws at their lower end: corners (0, 50-10-32, 60-10-32) = (0, 8, 18).
+      B. volume 16x48x200 (shorter than the patch in D and H): D needs 16 voxels of padding -> the only corner is -8; H is narrower
+         than the box -> centred, 24 - 32 = -8, and NO jitter draw; W: centre 100, jitter +-10, upper end -> 100 + 10 - 32 = 78.
+      C. volume 33x64x70, patch 32x64x64: D free in [0, 1]; H has no margin (32 - 32 = 0) -> no draw, corner 0; W: centre 35, margins
+         min(10, 35-32, 70-35-32) = 3 -> jitter +-3, middle of [-3, 3] = 0 -> corner 3.
+      D. as A with a forced foreground voxel (z, y, x) = (39, 5, 7): D corner = clamp(39 - 16, 0, 8) = 8; H / W are in-plane (jitter)."""
+    from medical_image_generation_amd.data import PatchSampler
+    ps = PatchSampler((32, 64, 64), batch_size=2)
+    r = _ScriptedRandint(["lo"] * 5)
+    monkeypatch.setattr(np.random, "randint", r)
+    assert ps.get_bbox((40, 100, 120), False, None) == ([0, 8, 18], [32, 72, 82])
+    assert r.calls == [(0, 9), (0, 37), (0, 57), (-10, 11), (-10, 11)]
+    r = _ScriptedRandint(["lo", "lo", "lo", "hi"])
+    monkeypatch.setattr(np.random, "randint", r)
+    assert ps.get_bbox((16, 48, 200), False, None) == ([-8, -8, 78], [24, 56, 142])
+    assert r.calls == [(-8, -7), (-8, -7), (0, 137), (-10, 11)]
+    r = _ScriptedRandint(["hi", "lo", "lo", "mid"])
+    monkeypatch.setattr(np.random, "randint", r)
+    assert ps.get_bbox((33, 64, 70), False, None) == ([1, 0, 3], [33, 64, 67])
+    assert r.calls == [(0, 2), (0, 1), (0, 7), (-3, 4)]
+    r = _ScriptedRandint(["lo"] * 3 + ["hi", "hi"])
+    monkeypatch.setattr(np.random, "randint", r)
+    monkeypatch.setattr(np.random, "choice", lambda a: a[0] if not isinstance(a, (int, np.integer)) else 0)
+    locs = {1: np.array([[39, 5, 7]]), 2: np.zeros((0, 3), int)}
+    assert ps.get_bbox((40, 100, 120), True, locs) == ([8, 28, 38], [40, 92, 102])
+    # 2-D (pseudo 3-D, one slice thick): the slice of the foreground voxel, in-plane centred
+    ps2 = PatchSampler((32, 32), batch_size=2)
+    r = _ScriptedRandint(["lo"] * 5)
+    monkeypatch.setattr(np.random, "randint", r)
+    assert ps2.get_bbox((5, 50, 40), True, {1: np.array([[2, 10, 12]])}) == ([2, 25 - 9 - 16, 20 - 4 - 16], [3, 32, 32])
+    assert r.calls == [(0, 5), (0, 19), (0, 9), (-9, 10), (-4, 5)]
+
+
+def test_batch_order_keeps_its_deck_across_epochs():
+    """CustomBatchSampler shuffles `self.indices` IN PLACE at the start of every epoch (DATA:615-616), so the second epoch's deck is
+    a permutation of the first epoch's, not of range(n): same seed, two epochs, against the oracle run twice on one list."""
+    from medical_image_generation_amd.data import BatchOrder
+    np.random.seed(11)
+    bo = BatchOrder(9, 2, number_of_steps=6)
+    e1, e2 = list(bo), list(bo)
+    np.random.seed(11)
+    idx = list(range(9))
+    want = []
+    for _ in range(2):
+        np.random.shuffle(idx)
+        deck, run = list(idx), []
+        while len(run) < 12:
+            if len(deck) < 2:
+                deck = list(idx)
+                np.random.shuffle(deck)
+            run += deck[:2]
+            deck = deck[2:]
+        want.append([[(0, run[2 * k]), (1, run[2 * k + 1])] for k in range(6)])
+    assert [e1, e2] == want and e1 != e2
+    # fewer samples than a batch: the reference keeps dealing short hands until the run is long enough
+    np.random.seed(1)
+    short = list(BatchOrder(3, 4, number_of_steps=2, shuffle=False))
+    assert short == [[(0, 0), (1, 1), (2, 2), (3, 0)], [(0, 1), (1, 2), (2, 0), (3, 1)]]
+
+
 def test_batch_order_uses_every_sample_before_repeating():
     from medical_image_generation_amd.data import BatchOrder
     np.random.seed(3)

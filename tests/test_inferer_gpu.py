@@ -78,6 +78,79 @@ def test_sample_loop_matches_oracle(graph):
     assert torch.isfinite(got).all() and err <= 3e-2  # bf16 UNet forward, 5 steps (same budget as the forward parity tests)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_sample_loop_with_concat_conditioning_matches_oracle(graph):
+    """sample(conditioning=, mode="concat"): model_input = cat([image, conditioning], dim=1) at every step (upstream
+    `generative.inferers.DiffusionInferer.sample`, source absent: PARITY UNPINNED; restated here as the loop below); only the
+    image channels are denoised, the condition channels stay as given."""
+    from medical_image_generation_amd.inferer import DDPMScheduler, DiffusionInferer
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    kw = dict(cases.UNET_CASES["unet_ldm"]["kwargs"], in_channels=9, out_channels=8)
+    ref = nets.DiffusionModelUNet(**kw)
+    sd = synth.state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, S)
+    ref.load_state_dict(sd)
+    net = DiffusionModelUNet(**kw)
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    sch = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205)
+    sch.set_timesteps(5)
+    steps = sch.timesteps.tolist()
+    shape = (2, 8, 8, 8, 8)
+    x0 = synth.tensor(S, "sample_noise", shape)
+    label = (synth.ellipsoid_volume(S, "label", (2, 1, 8, 8, 8)) > 0).float()
+    zs = [synth.tensor(S, f"sample_z{i}", shape) for i in range(len(steps))]
+    oracle = step.DDPMSchedule()
+    x = x0.clone()
+    with torch.no_grad():
+        for i, t in enumerate(steps):
+            eps = ref(torch.cat([x, label], dim=1), torch.full((shape[0],), t, dtype=torch.int64))
+            x, _ = oracle.step(eps, t, x, zs[i], clip_sample=True)
+    inf = DiffusionInferer(sch)
+    got = inf.sample(x0.cuda(), net, sch, conditioning=label.cuda(), mode="concat", verbose=False, noises=[z.cuda() for z in zs], use_graph=graph)
+    err = float((got.cpu() - x).norm() / x.norm())
+    print(f"\n[concat-conditioned sample loop graph={graph}] rel-L2 after {len(steps)} steps: {err:.3e}")
+    assert got.shape == shape and torch.isfinite(got).all() and err <= 3e-2
+    with pytest.raises(ValueError):
+        inf.sample(x0.cuda(), net, sch, verbose=False)  # 8 channels into a 9-channel net
+    with pytest.raises(NotImplementedError):
+        inf.sample(x0.cuda(), net, sch, conditioning=label.cuda(), mode="film", verbose=False)
+
+
+def test_sample_loop_with_crossattn_conditioning_matches_oracle():
+    """sample(conditioning=context, mode="crossattn") on a with_conditioning=True net (train_ldm.py:349-365's call shape with a
+    context): the context is the model's `context=` at every step."""
+    from medical_image_generation_amd.inferer import DDPMScheduler, DiffusionInferer
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    c = cases.UNET_CASES["unet2d_xattn"]
+    ref = nets.DiffusionModelUNet(**c["kwargs"])
+    sd = synth.state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, S)
+    ref.load_state_dict(sd)
+    net = DiffusionModelUNet(**c["kwargs"])
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    sch = DDPMScheduler(num_train_timesteps=1000, schedule="scaled_linear_beta", beta_start=0.0015, beta_end=0.0205)
+    sch.set_timesteps(4)
+    steps = sch.timesteps.tolist()
+    shape = c["shape"]
+    x0 = synth.tensor(S, "sample_noise", shape)
+    context = synth.tensor(S, "context", c["context"])
+    zs = [synth.tensor(S, f"sample_z{i}", shape) for i in range(len(steps))]
+    oracle = step.DDPMSchedule()
+    x = x0.clone()
+    with torch.no_grad():
+        for i, t in enumerate(steps):
+            eps = ref(x, torch.full((shape[0],), t, dtype=torch.int64), context=context)
+            x, _ = oracle.step(eps, t, x, zs[i], clip_sample=True)
+    inf = DiffusionInferer(sch)
+    for graph in (False, True):
+        got = inf.sample(x0.cuda(), net, sch, conditioning=context.cuda(), verbose=False, noises=[z.cuda() for z in zs], use_graph=graph)
+        err = float((got.cpu() - x).norm() / x.norm())
+        print(f"\n[cross-attention-conditioned sample loop graph={graph}] rel-L2 after {len(steps)} steps: {err:.3e}")
+        assert torch.isfinite(got).all() and err <= 3e-2
+    with pytest.raises(ValueError):
+        inf.sample(x0.cuda(), net, sch, verbose=False)  # a conditioned net needs its context
+
+
 def test_latent_inferer_decodes_through_the_autoencoder():
     """LatentDiffusionInferer.sample = latent sample loop, then autoencoder.decode_stage_2_outputs(latents / scale_factor)
     (train_ldm.py:112, 362-364)."""

@@ -214,6 +214,55 @@ def test_conditioned_step_matches_oracle(graph):
         tr.forward_backward(x0.cuda(), noise.cuda(), t.cuda())  # a conditioned net needs its context
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_concat_conditioned_step_matches_oracle(graph):
+    """BASELINE configs[4]: label-channel (channel-concatenation) conditioning on the EXACT C5 net kwargs (in 9 / out 8, one head of
+    512 / 768) at 12^3 with BATCH 2: the 8 latent channels are noised, the label channel is written un-noised behind them, the net
+    predicts 8 channels and the MSE target is the latents' noise (the inferer's `condition=, mode="concat"` of train_ddpm.py:191,
+    restated in oracle/step.py).  Batch 2 is the case a 9-channel target read with C = 8 got wrong."""
+    from medical_image_generation_amd.trainer import DDPMTrainer
+    c, ref, net = _nets("unet_c5")
+    tr = DDPMTrainer(net, lr=cases.STEP_LR, optimizer="AdamW", max_grad_norm=1.0)
+    sched = step.DDPMSchedule()
+    shape = (2, 8, 12, 12, 12)
+    x0 = synth.tensor(S, "latents", shape)
+    noise = synth.tensor(S, "noise0", shape)
+    label = (synth.ellipsoid_volume(S, "label", (2, 1, 12, 12, 12)) > 0).float()  # a binary mask, like a segmentation channel
+    t = torch.tensor([42, 873])
+    loss_ref, _ = step.ddpm_loss(ref, sched, x0, noise, t, condition=label)
+    loss_ref.backward()
+    args = (x0.cuda(), noise.cuda(), t.cuda(), None, None, label.cuda())
+    if graph:
+        tr.capture(*args)
+        tr._g_fb.replay()
+    else:
+        tr.forward_backward(*args)
+    names = [n for n, p in ref.named_parameters() if p.grad is not None]
+    g_ref = torch.cat([dict(ref.named_parameters())[n].grad.flatten() for n in names])
+    g_hip = torch.cat([tr.arena.gview(n).cpu().flatten() for n in names])
+    e = float((g_hip - g_ref).norm() / g_ref.norm())
+    print(f"\n[C5 concat-conditioned step b2 graph={graph}] loss {float(tr.loss):.6f} vs {float(loss_ref):.6f}; gradient rel-L2 {e:.3e}")
+    assert abs(float(tr.loss) - float(loss_ref)) <= 1e-2 * float(loss_ref) and e <= 4e-2
+    # channel bookkeeping is checked, not assumed: noising all 9 input channels cannot produce an 8-channel target ...
+    x9 = torch.cat([x0, label], dim=1).cuda().contiguous()
+    with pytest.raises(ValueError, match="predicts 8 channels"):
+        tr.forward_backward(x9, torch.randn_like(x9), t.cuda())
+    # ... and the input channel count must add up
+    with pytest.raises(ValueError, match="expected number of channels"):
+        tr.forward_backward(x0.cuda(), noise.cuda(), t.cuda())
+    with pytest.raises(ValueError):
+        tr.forward_backward(x0.cuda(), noise.cuda(), t.cuda(), None, None, label.cuda()[:, :, :6])  # spatial mismatch
+    # the autograd-edge form: DiffusionInferer.__call__(condition=, mode="concat") is the same forward
+    from medical_image_generation_amd.inferer import DDPMScheduler, DiffusionInferer
+    inferer = DiffusionInferer(DDPMScheduler(1000, "scaled_linear_beta", beta_start=0.0015, beta_end=0.0205))
+    with torch.no_grad():
+        pred = inferer(inputs=x0.cuda(), diffusion_model=net, noise=noise.cuda(), timesteps=t.cuda(), condition=label.cuda(), mode="concat")
+    l2 = float(torch.nn.functional.mse_loss(pred.float(), noise.cuda()))
+    assert pred.shape == shape and abs(l2 - float(loss_ref)) <= 1e-2 * float(loss_ref)
+    with pytest.raises(NotImplementedError):
+        inferer(inputs=x0.cuda(), diffusion_model=net, noise=noise.cuda(), timesteps=t.cuda(), condition=label.cuda(), mode="film")
+
+
 def test_v_prediction_step_matches_oracle():
     """prediction_type = "v_prediction" (train_ldm.py:163-165): the target is scheduler.get_velocity(x0, noise, t)."""
     from medical_image_generation_amd.trainer import DDPMSchedule, DDPMTrainer
@@ -326,6 +375,163 @@ def test_backward_cut_is_sound_and_split_graphs_agree():
     # tensors whose exact gradient is zero (to_k.bias, ...), so they agree to a few 1e-4, not to 1e-8
     assert abs(l_a[0] - l_b[0]) <= 2e-6 * abs(l_a[0]) and eg <= 1e-6
     assert abs(l_a[1] - l_b[1]) <= 1e-3 * abs(l_a[1]) and e <= 1e-3
+
+
+_CUT_VARIANTS = {
+    # the variants that change WHICH parameters complete late in the backward: resnet resamplers, cross-attention blocks,
+    # the class-embedding table (written by the time-embedding backward, the very last tape entry), per-block recomputation
+    "updown": dict(case="unet2d_updown", over=dict(num_channels=(16, 32, 32, 64), attention_levels=(False, False, False, True),
+                                                   num_head_channels=(0, 0, 0, 16), num_res_blocks=1,
+                                                   strides=[[1, 1]] + [[2, 2]] * 3, kernel_sizes=[[3, 3]] + [[2, 2]] * 3,
+                                                   paddings=[[1, 1]] + [[0, 0]] * 3), shape=(2, 1, 32, 32)),
+    "xattn": dict(case="unet2d_xattn", over=dict(num_channels=(32, 32, 64, 64), attention_levels=(False, False, True, True),
+                                                 num_head_channels=(0, 0, 32, 32), strides=[[1, 1]] + [[2, 2]] * 3,
+                                                 kernel_sizes=[[3, 3]] * 4, paddings=[[1, 1]] * 4), shape=(2, 1, 32, 32), context=(2, 5, 16)),
+    "class": dict(case="unet2d_class", over=dict(num_channels=(16, 32, 32, 32), attention_levels=(False, False, False, True),
+                                                 num_head_channels=(0, 0, 0, 16), strides=[[1, 1]] + [[2, 2]] * 3,
+                                                 kernel_sizes=[[3, 3]] * 4, paddings=[[1, 1]] * 4), shape=(2, 1, 32, 32), labels=(1, 3)),
+    "ckpt": dict(case="unet3d", over=dict(num_channels=(32, 32, 64, 64), attention_levels=(False, False, False, True),
+                                          num_head_channels=(0, 0, 0, 32), strides=[[1] * 3] + [[2] * 3] * 3, kernel_sizes=[[3] * 3] * 4,
+                                          paddings=[[1] * 3] * 4), shape=(2, 1, 16, 16, 16), ckpt=True),
+}
+
+
+@pytest.mark.parametrize("variant", list(_CUT_VARIANTS))
+def test_backward_cut_is_sound_for_every_block_family(variant):
+    """The claim of test_backward_cut_is_sound_and_split_graphs_agree -- at the cut mark every gradient of [n_late, n_trainable) is
+    final -- on 4-level nets with resblock_updown, with_conditioning, num_class_embeds and use_checkpointing (each changes which
+    parameters the tail of the backward still writes), and the two-graph capture against the one-graph capture on the same nets."""
+    from medical_image_generation_amd.trainer import DDPMTrainer
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    v = _CUT_VARIANTS[variant]
+    kw = dict(cases.UNET_CASES[v["case"]]["kwargs"], **v["over"])
+
+    def make():
+        torch.manual_seed(5)
+        net = DiffusionModelUNet(**kw)
+        for p in net.parameters():
+            if float(p.detach().abs().max()) == 0:
+                torch.nn.init.normal_(p, std=0.02)
+        net.use_checkpointing = bool(v.get("ckpt"))
+        return net.cuda()
+
+    shape = v["shape"]
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x0 = torch.rand(shape, device="cuda", generator=g)
+    noise = torch.randn(shape, device="cuda", generator=g)
+    t = torch.tensor([100, 900], device="cuda")
+    labels = torch.tensor(v["labels"], device="cuda") if "labels" in v else None
+    context = torch.randn(v["context"], device="cuda", generator=g) if "context" in v else None
+    args = (x0, noise, t, labels, context)
+    tr = DDPMTrainer(make(), lr=1e-4)
+    a = tr.arena
+    assert 0 < a.n_late < a.n_trainable
+    snap = {}
+    tr.forward_backward(*args, on_cut=lambda: snap.setdefault("early", a.grad[a.n_late:a.n_trainable].clone()))
+    assert "early" in snap and float(snap["early"].abs().max()) > 0
+    assert torch.equal(snap["early"], a.grad[a.n_late:a.n_trainable]), f"{variant}: an early-segment gradient changed after the cut mark"
+    assert float(a.grad[:a.n_late].abs().max()) > 0
+    # every trainable tensor is in exactly one segment and received a gradient
+    for name, _, trainable in tr.model._entries:
+        if trainable:
+            assert float(a.gview(name).abs().max()) > 0 or name.endswith(("to_k.bias",)), f"{variant}: no gradient reached {name}"
+    out = []
+    for split in (False, True):
+        trn = DDPMTrainer(make(), lr=1e-4)
+        trn._force_split = split
+        trn.capture(*args)
+        assert (trn._g_fb2 is not None) == split
+        l0 = float(trn.step_graph())
+        out.append((l0, trn.arena.grad[:trn.arena.n_trainable].clone()))
+    (l_a, g_a), (l_b, g_b) = out
+    eg = float((g_a - g_b).norm() / g_a.norm())
+    print(f"\n[cut {variant}] n_late {a.n_late} of {a.n_trainable}; one-graph vs two-graph: loss {l_a} / {l_b}, gradient rel-L2 {eg:.2e}")
+    assert abs(l_a - l_b) <= 1e-5 * abs(l_a) and eg <= 1e-5
+    # overlap=False: the plain schedule (one backward graph, exchange afterwards) is what a capture gives even when a split is forced
+    trp = DDPMTrainer(make(), lr=1e-4, overlap=False)
+    trp._force_split = True
+    trp.capture(*args)
+    assert trp._g_fb2 is None
+
+
+def test_rccl_collectives_between_graph_replays_one_rank():
+    """The data-parallel step as world > 1 runs it, on the one GPU a test box has: a ONE-RANK process group on the real backend
+    ("nccl" = RCCL), forward + backward captured as TWO hipGraphs, the early segment's all-reduce issued asynchronously between the
+    replays, the late segment's after the second, then the optimizer graph.  A sum over one rank changes nothing, so gradients and
+    parameters must equal the run without any exchange: this proves that RCCL calls between replays neither break the capture
+    pools nor the ordering (what it cannot show is bandwidth or CU sharing with the persistent conv kernels: DESIGN.md section 6)."""
+    import os
+    import socket
+    import bench
+    import torch.distributed as dist
+    from medical_image_generation_amd.trainer import DDPMTrainer
+    from medical_image_generation_amd.unet import DiffusionModelUNet
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    try:
+        def make():
+            torch.manual_seed(5)
+            net = DiffusionModelUNet(**bench.C4)
+            for p in net.parameters():
+                if float(p.detach().abs().max()) == 0:
+                    torch.nn.init.normal_(p, std=0.02)
+            return net.cuda()
+
+        d = 32
+        x0 = bench.synthetic_volume((2, 1, d, d, d), 3, torch.device("cuda"))
+        g = torch.Generator(device="cuda").manual_seed(1)
+        noise = torch.randn((2, 1, d, d, d), device="cuda", generator=g)
+        t = torch.tensor([100, 900], device="cuda")
+        out = []
+        for exchange in (False, True):
+            tr = DDPMTrainer(make(), lr=1e-4, bucket_mb=16)  # 16 MiB slices: the 165 MB early segment goes out as 10 collectives
+            tr._force_split = True
+            tr._force_exchange = exchange
+            tr.capture(x0, noise, t)
+            assert tr._g_fb2 is not None
+            l0 = float(tr.step_graph())
+            g0 = tr.arena.grad[:tr.arena.n_trainable].clone()
+            l1 = float(tr.step_graph())
+            out.append((l0, l1, g0, tr.arena.data[:tr.arena.n_trainable].clone()))
+            # eager form of the same schedule (start_early from the tape's cut mark)
+            tr.step(x0, noise, t)
+            torch.cuda.synchronize()
+            assert bool(torch.isfinite(tr.loss).all())
+        (la0, la1, ga, pa), (lb0, lb1, gb, pb) = out
+        eg, ep = float((ga - gb).norm() / ga.norm()), float((pa - pb).norm() / pa.norm())
+        print(f"\n[RCCL one-rank exchange between replays] losses {la0:.6f}/{la1:.6f} vs {lb0:.6f}/{lb1:.6f}; gradient rel-L2 {eg:.2e}, "
+              f"parameters {ep:.2e}")
+        assert abs(la0 - lb0) <= 1e-5 * abs(la0) and eg <= 1e-5 and ep <= 1e-6
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_two_ranks_child_process():
+    """`python bench.py --gpus 2` as the driver's N > 1 run starts it, rehearsed on one GPU: bench.py launches its own ranks through
+    torch.distributed.run as a CHILD process (never re-exec'ing a process that has touched the GPU), both ranks share this card with
+    the gloo backend, capture the split graphs, exchange gradients and rank 0 prints the JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--size", "32", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 2 and rec["config"]["parallelism"] == "dp2"
+    assert rec["value"] > 0 and rec["scaling"] == "weak" and rec["loss"] == rec["loss"] and abs(rec["loss"]) < 1e3
+    assert rec["config"]["hipgraph"] is True
 
 
 def test_graph_survives_other_shape_forward():

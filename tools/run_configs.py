@@ -62,10 +62,10 @@ elif which in ("c3b", "c5", "c3b_ldm", "c5_ckpt"):  # latent UNet the reference'
     ldm, ckpt = which == "c3b_ldm", which == "c5_ckpt"
     which = {"c3b_ldm": "c3b", "c5_ckpt": "c5"}.get(which, which)
     cin = 8 if which == "c3b" else 9
-    kw = dict(spatial_dims=3, in_channels=cin, out_channels=8 if which == "c3b" else 9, num_res_blocks=2, num_channels=[256, 512, 768],
+    kw = dict(spatial_dims=3, in_channels=cin, out_channels=8, num_res_blocks=2, num_channels=[256, 512, 768],
               attention_levels=[False, True, True], num_head_channels=[0, 512, 768], norm_num_groups=32,
               strides=iso(3), kernel_sizes=[[3] * 3] * 3, paddings=[[1] * 3] * 3)
-    shape = (4, 8, 32, 32, 32) if which == "c3b" else (1, 9, 40, 40, 40)
+    shape = (4, 8, 32, 32, 32) if which == "c3b" else (1, 8, 40, 40, 40)  # (C5: + 1 un-noised label channel, `condition`)
     vox_per_sample = 128 ** 3 if which == "c3b" else 160 ** 3
 dev = torch.device("cuda")
 torch.manual_seed(0)
@@ -92,7 +92,11 @@ if ldm:
 else:
     tr = DDPMTrainer(net, lr=2e-5)
     x0 = torch.rand(shape, device=dev)
-    tr.capture(x0, noise, t)
+    if which == "c5":  # BASELINE configs[4]: label-channel conditioning = a binary mask concatenated un-noised behind the 8 noised latents
+        cond = (torch.rand((shape[0], 1) + shape[2:], device=dev) > 0.5).float()
+        tr.capture(x0, noise, t, None, None, cond)
+    else:
+        tr.capture(x0, noise, t)
 for _ in range(2):
     tr.step_graph()
 torch.cuda.synchronize()
@@ -102,7 +106,7 @@ for _ in range(steps):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
 c = E.Ctx(tr.arena, net._plans, grad_enabled=True)
-dims = (shape[0],) + tuple(shape[2:]) + (shape[1],)
+dims = (shape[0],) + tuple(shape[2:]) + (kw["in_channels"],)
 net._run(c, torch.zeros(dims, dtype=torch.bfloat16, device=dev), t, need_dx=False)
 c.tape.fns.clear()
 fl = c.flops_fwd + c.flops_bwd
