@@ -506,7 +506,9 @@ def test_rccl_collectives_between_graph_replays_one_rank():
         eg, ep = float((ga - gb).norm() / ga.norm()), float((pa - pb).norm() / pa.norm())
         print(f"\n[RCCL one-rank exchange between replays] losses {la0:.6f}/{la1:.6f} vs {lb0:.6f}/{lb1:.6f}; gradient rel-L2 {eg:.2e}, "
               f"parameters {ep:.2e}")
-        assert abs(la0 - lb0) <= 1e-5 * abs(la0) and eg <= 1e-5 and ep <= 1e-6
+        # gradients: fp32-atomic summation-order noise only; parameters / second loss: Adam turns that noise into +-lr steps on tensors whose
+        # exact gradient is zero, so they agree to ~1e-4 (the same floor as the one-graph vs two-graph comparison above)
+        assert abs(la0 - lb0) <= 2e-6 * abs(la0) and eg <= 1e-6 and abs(la1 - lb1) <= 1e-3 * abs(la1) and ep <= 1e-3
     finally:
         dist.destroy_process_group()
 
