@@ -26,7 +26,7 @@ def test_ddpm_step_kernel_matches_closed_form():
         eps_cl = ops.to_channels_last(eps.cuda())
         x_cl = torch.empty_like(eps_cl)
         td = torch.tensor([t], device="cuda")
-        call("mi_ddpm_step", ptr(xd), ptr(eps_cl), ptr(zd), ptr(sch.coefficients("cuda")), ptr(td), ptr(x_cl), shape[0], shape[1], 4 * 6 * 5, 1)
+        call("mi_ddpm_step", ptr(xd), ptr(eps_cl), ptr(zd), ptr(sch.coefficients("cuda")), ptr(td), ptr(x_cl), shape[1], shape[0], shape[1], 4 * 6 * 5, 1)
         assert float((xd.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
         assert float((ops.to_channels_first(x_cl).cpu() - want).abs().max()) <= 1e-2 * float(want.abs().max())
     # v-prediction: the model output is the velocity
@@ -34,7 +34,7 @@ def test_ddpm_step_kernel_matches_closed_form():
     refv = step.DDPMSchedule(prediction_type="v_prediction")
     want, _ = refv.step(eps, 500, x, z, clip_sample=True)
     xd, td = x.cuda(), torch.tensor([500], device="cuda")
-    call("mi_ddpm_step", ptr(xd), ptr(eps_cl), ptr(zd), ptr(schv.coefficients("cuda")), ptr(td), None, shape[0], shape[1], 4 * 6 * 5, 3)
+    call("mi_ddpm_step", ptr(xd), ptr(eps_cl), ptr(zd), ptr(schv.coefficients("cuda")), ptr(td), None, 0, shape[0], shape[1], 4 * 6 * 5, 3)
     assert float((xd.cpu() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
     pv, _ = schv.step(eps, 0, x)
     wv, _ = refv.step(eps, 0, x, None)

@@ -315,12 +315,18 @@ def test_train_glue(ops):
     out = torch.empty((n, *dims, c), dtype=torch.bfloat16, device=dev)
     sa, so = acp.sqrt().to(dev), (1 - acp).sqrt().to(dev)
     x0d, nd, td = x0.to(dev), noise.to(dev), t.to(dev)  # keep alive: calls are asynchronous
-    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(out), None, n, c, v, 1000)
+    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), None, 0, ptr(out), None, n, c, v, 1000)
     ref = acp[t].sqrt().view(n, 1, 1, 1, 1) * x0 + (1 - acp[t]).sqrt().view(n, 1, 1, 1, 1) * noise
     check(cf(out), ref, 1e-2, "qsample")
     vel = torch.empty_like(x0d)  # v-prediction target (scheduler.get_velocity, T-LDM:163-165)
-    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(out), ptr(vel), n, c, v, 1000)
+    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), None, 0, ptr(out), ptr(vel), n, c, v, 1000)
     check(vel.cpu(), acp[t].sqrt().view(n, 1, 1, 1, 1) * noise - (1 - acp[t]).sqrt().view(n, 1, 1, 1, 1) * x0, 1e-6, "velocity target")
+    # mode="concat": two un-noised condition channels behind the c noised ones (pitch c + 2), batch 2
+    cond = rnd(n, 2, *dims, seed=5)
+    condd = cond.to(dev)
+    out2 = torch.empty((n, *dims, c + 2), dtype=torch.bfloat16, device=dev)
+    call("mi_qsample", ptr(x0d), ptr(nd), ptr(sa), ptr(so), ptr(td), ptr(condd), 2, ptr(out2), None, n, c, v, 1000)
+    check(cf(out2), torch.cat([ref, cond], dim=1), 1e-2, "qsample + concat condition")
     pred = rnd(n, c, *dims, seed=2)
     pr = pred.clone().requires_grad_(True)
     loss_ref = F.mse_loss(pr, noise)
