@@ -7,6 +7,8 @@
 // that conv prologues / the apply kernel consume, so "normalise" is a single FMA per element downstream.
 // Backward uses the same two-level shape: partial sums of du and du*x, a per-(n, group) finish producing the three
 // coefficients of  dx = a*du + b*x + c  per (n, channel), and a streaming apply.
+#include <stdlib.h>
+
 #include "common.h"
 #include "medimgen_hip.h"
 
@@ -72,22 +74,26 @@ __device__ __forceinline__ void block_fold(float (&a)[8], float (&b)[8], float* 
 
 // partial[n][c][chunk][2] = (sum x, sum x^2) over the chunk's voxels
 __global__ void __launch_bounds__(kT) k_gn_partial(const bf16* __restrict__ x, int cstride, float* __restrict__ partial, int C,
-                                                   int64_t V, int64_t vchunk) {
+                                                   int64_t V, int64_t vchunk, int sweep) {
   extern __shared__ float sm[];  // [rows][C][2]
   const int C8 = C / 8, rows = kT / C8;
   const int cg = threadIdx.x % C8, r = threadIdx.x / C8;
   const int n = blockIdx.y;
-  const int64_t v0 = blockIdx.x * vchunk, v1 = (v0 + vchunk < V) ? v0 + vchunk : V;
+  // sweep: the blocks of an image advance through it TOGETHER (block b takes voxel lanes b*rows + r of every stride of gridDim.x*rows
+  // voxels) instead of each block walking its own chunk: memory is touched front to back in time, so that the pass that follows can
+  // walk back to front and meet the lines this one touched last while they are still in the 256 MiB Infinity Cache (mi_gn_bwd)
+  const int64_t step = sweep ? (int64_t)gridDim.x * rows : rows;
+  const int64_t v0 = sweep ? (int64_t)blockIdx.x * rows : blockIdx.x * vchunk, v1 = sweep ? V : ((v0 + vchunk < V) ? v0 + vchunk : V);
   float s[8], q[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
   if (r < rows) {
     const bf16* base = x + (int64_t)n * V * cstride + cg * 8;
-    for (int64_t v = v0 + r; v < v1; v += 4 * rows) {  // 4 independent 16-byte loads in flight per lane
+    for (int64_t v = v0 + r; v < v1; v += 4 * step) {  // 4 independent 16-byte loads in flight per lane
       u32x4 raw[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        int64_t vk = v + (int64_t)k * rows;
+        int64_t vk = v + (int64_t)k * step;
         u32x4 z = {0u, 0u, 0u, 0u};
         raw[k] = vk < v1 ? *(const u32x4*)(base + vk * cstride) : z;
       }
@@ -173,20 +179,23 @@ __global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ p
 // are in flight per lane.
 template <bool SILU>
 __global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int xcs, const float* __restrict__ scale_shift,
-                                                 bf16* __restrict__ y, int ycs, int C8, int64_t V) {
+                                                 bf16* __restrict__ y, int ycs, int C8, int64_t V, int rev) {
   const int C = C8 * 8;
   const int tid = blockIdx.x * kT + threadIdx.x;
   const int cg = tid % C8, R = gridDim.x * kT / C8;
   const int64_t n = blockIdx.y;
   float sc[8], sh[8];
   load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
-  const bf16* xb = x + n * V * xcs + cg * 8;
-  bf16* yb = y + n * V * ycs + cg * 8;
+  // rev: walk the image back to front (voxel V-1-v): right behind a statistics pass that swept it front to back, the lines that
+  // pass touched last are met first, while they are still in the Infinity Cache
+  const bf16* xb = x + n * V * xcs + cg * 8 + (rev ? (V - 1) * xcs : 0);
+  bf16* yb = y + n * V * ycs + cg * 8 + (rev ? (V - 1) * ycs : 0);
+  const int64_t xs = rev ? -(int64_t)xcs : xcs, ys = rev ? -(int64_t)ycs : ycs;
   for (int64_t v = tid / C8; v < V; v += 4 * (int64_t)R) {
     u32x4 raw[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (v + k * (int64_t)R < V) raw[k] = *(const u32x4*)(xb + (v + k * (int64_t)R) * xcs);
+      if (v + k * (int64_t)R < V) raw[k] = *(const u32x4*)(xb + (v + k * (int64_t)R) * xs);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       if (v + k * (int64_t)R >= V) break;
@@ -196,7 +205,7 @@ __global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int
         float u = f.v[j] * sc[j] + sh[j];
         f.v[j] = SILU ? silu_f(u) : u;
       }
-      *(u32x4*)(yb + (v + k * (int64_t)R) * ycs) = pack8(f);
+      *(u32x4*)(yb + (v + k * (int64_t)R) * ys) = pack8(f);
     }
   }
 }
@@ -205,12 +214,13 @@ __global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int
 template <bool SILU>
 __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                        const float* __restrict__ scale_shift, float* __restrict__ partial, int C,
-                                                       int64_t V, int64_t vchunk) {
+                                                       int64_t V, int64_t vchunk, int sweep) {
   extern __shared__ float sm[];
   const int C8 = C / 8, rows = kT / C8;
   const int cg = threadIdx.x % C8, r = threadIdx.x / C8;
   const int n = blockIdx.y;
-  const int64_t v0 = blockIdx.x * vchunk, v1 = (v0 + vchunk < V) ? v0 + vchunk : V;
+  const int64_t step = sweep ? (int64_t)gridDim.x * rows : rows;  // (see k_gn_partial)
+  const int64_t v0 = sweep ? (int64_t)blockIdx.x * rows : blockIdx.x * vchunk, v1 = sweep ? V : ((v0 + vchunk < V) ? v0 + vchunk : V);
   float s1[8], s2[8], sc[8], sh[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
@@ -218,11 +228,11 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ 
     load_ss(scale_shift + (int64_t)n * C * 2, cg * 8, sc, sh);
     const bf16* xb = x + (int64_t)n * V * xcs + cg * 8;
     const bf16* gb = g + (int64_t)n * V * gcs + cg * 8;
-    for (int64_t v = v0 + r; v < v1; v += 4 * rows) {  // 8 independent 16-byte loads in flight per lane
+    for (int64_t v = v0 + r; v < v1; v += 4 * step) {  // 8 independent 16-byte loads in flight per lane
       u32x4 rx[4], rg[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        int64_t vk = v + (int64_t)k * rows;
+        int64_t vk = v + (int64_t)k * step;
         u32x4 z = {0u, 0u, 0u, 0u};
         rx[k] = vk < v1 ? *(const u32x4*)(xb + vk * xcs) : z;
         rg[k] = vk < v1 ? *(const u32x4*)(gb + vk * gcs) : z;  // g = 0 beyond the chunk -> contributes nothing
@@ -293,7 +303,7 @@ template <bool SILU>
 __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                      const float* __restrict__ scale_shift, const float* __restrict__ coef,
                                                      const bf16* __restrict__ add, int acs, const bf16* __restrict__ add2, int a2cs,
-                                                     bf16* __restrict__ dx, int dcs, int C8, int64_t V) {
+                                                     bf16* __restrict__ dx, int dcs, int C8, int64_t V, int rev) {
   const int C = C8 * 8;
   const int tid = blockIdx.x * kT + threadIdx.x;
   const int cg = tid % C8, R = gridDim.x * kT / C8;
@@ -314,8 +324,8 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
     u32x4 rx[2], rg[2], ra[2], ra2[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int64_t vk = v + k * (int64_t)R;
-      if (vk < V) {
+      const int64_t vf = v + k * (int64_t)R, vk = rev ? V - 1 - vf : vf;  // rev: back to front (see k_gn_apply)
+      if (vf < V) {
         rx[k] = *(const u32x4*)(xb + vk * xcs);
         rg[k] = *(const u32x4*)(gb + vk * gcs);
         if (ab) ra[k] = *(const u32x4*)(ab + vk * acs);
@@ -324,8 +334,8 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int64_t vk = v + k * (int64_t)R;
-      if (vk >= V) break;
+      const int64_t vf = v + k * (int64_t)R, vk = rev ? V - 1 - vf : vf;
+      if (vf >= V) break;
       F8 fx = unpack8(rx[k]), fg = unpack8(rg[k]), o;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -367,6 +377,15 @@ inline int64_t pick_vchunk(int64_t V) {
   if (vc < 16) vc = 16;
   return vc;
 }
+// MI_GN_SWEEP (A/B knob, default 0 = every block walks its own chunk, both passes front to back).  Bit 0: the statistics passes sweep an
+// image front to back with all blocks abreast and the backward's apply pass walks it back to front, so that it meets the lines the
+// partial pass touched last while they could still be in the 256 MiB Infinity Cache; bit 1: the forward apply pass walks back to front
+// too.  Measured (round 3, profiles/r03b_ab_gn_sweep.log, same box, interleaved): 24.20 ms/step with 0, 24.25 with 1, 24.26 with 3;
+// mi_gn_bwd at 32 ch x 128^3 back to back: 139 us (0) vs 146 (1).  The two passes of a 268 MB working set gain nothing from the order.
+inline int gn_sweep() {
+  static const int v = [] { const char* e = getenv("MI_GN_SWEEP"); return e ? atoi(e) : 0; }();
+  return v;
+}
 inline bool bad_c(int C, int G) { return C <= 0 || (C & 7) || C > 2048 || G <= 0 || C % G != 0; }
 
 }  // namespace
@@ -386,7 +405,7 @@ int mi_gn_stats(const void* x, int x_cstride, int N, int64_t V, int C, int G, fl
   int chunks = (int)((V + vc - 1) / vc);
   int rows = kT / (C / 8);
   hipLaunchKernelGGL(k_gn_partial, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)x, x_cstride,
-                     (float*)workspace, C, V, vc);
+                     (float*)workspace, C, V, vc, gn_sweep() & 1);
   hipLaunchKernelGGL(k_gn_finalize, dim3(N * G), dim3(256), 0, st, (const float*)workspace, chunks, C, (const float*)nullptr, 0, C, G, V, eps,
                      gamma, beta, scale_shift, mean_rstd);
   MI_CHECK_LAUNCH();
@@ -408,7 +427,8 @@ int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y,
   if (C <= 0 || (C & 7) || (x_cstride & 7) || (y_cstride & 7) || N <= 0 || V <= 0) return MI_ERR_BAD_ARG;
   int64_t grid = apply_grid(V * (C / 8), C / 8, N);
   auto k = silu ? k_gn_apply<true> : k_gn_apply<false>;
-  hipLaunchKernelGGL(k, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)x, x_cstride, scale_shift, (bf16*)y, y_cstride, C / 8, V);
+  hipLaunchKernelGGL(k, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)x, x_cstride, scale_shift, (bf16*)y, y_cstride, C / 8, V,
+                     gn_sweep() & 2 ? 1 : 0);
   MI_CHECK_LAUNCH();
   return 0;
 }
@@ -425,13 +445,13 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   int rows = kT / (C / 8);
   auto kp = silu ? k_gn_bwd_partial<true> : k_gn_bwd_partial<false>;
   hipLaunchKernelGGL(kp, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride, (const bf16*)x,
-                     x_cstride, scale_shift, (float*)workspace, C, V, vc);
+                     x_cstride, scale_shift, (float*)workspace, C, V, vc, gn_sweep() & 1);
   hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(N * G), dim3(256), sizeof(float) * 2 * (size_t)(C / G), st, (const float*)workspace, chunks, C,
                      G, V, gamma, mean_rstd, coef, dgamma, dbeta);
   int64_t grid = apply_grid(V * (C / 8), C / 8, N);
   auto ka = silu ? k_gn_bwd_apply<true> : k_gn_bwd_apply<false>;
   hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift, coef,
-                     (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V);
+                     (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V, gn_sweep() & 1);
   MI_CHECK_LAUNCH();
   return 0;
 }
