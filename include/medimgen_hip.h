@@ -75,6 +75,12 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
 typedef struct mi_conv_plan mi_conv_plan;
 int mi_conv_plan_create(mi_conv_plan** plan, int N, int Di, int Hi, int Wi, int Cin, int Cout, const int* kernel3, const int* stride3,
                         const int* padding3);
+/* Upsample.forward of the reference: nearest x2 interpolation on all three axes followed by the k3 s1 p1 `Convolution`
+ * (diffusion_model_unet_with_strides.py:569-588; autoencoderkl_with_strides.py Upsample), as ONE op: x [N][D][H][W][Cin] -> y
+ * [N][2D][2H][2W][Cout] without the up-sampled tensor in HBM (8 phase convolutions of 2x2x2 taps on the coarse tensor).  The plan is
+ * used with mi_conv_pack_weights / mi_conv_fwd / mi_conv_dgrad / mi_conv_wgrad like the others (weights: the conv's
+ * [Cout][Cin][3][3][3]; dx / x are the COARSE tensor).  MI_ERR_UNSUPPORTED for D == 1 (2-D nets keep mi_upsample_nearest_* + conv). */
+int mi_upconv_plan_create(mi_conv_plan** out, int N, int D, int H, int W, int Cin, int Cout);
 int mi_conv_plan_destroy(mi_conv_plan* plan);
 int mi_conv_plan_out_dims(const mi_conv_plan* plan, int* dims3);
 /* fp32 master weight (torch layout) -> packed bf16 MFMA fragments for forward and data-gradient; call after every update */

@@ -35,6 +35,7 @@ _SIGS = {
     "mi_gn_apply": [_p, _i, _p, _p, _i, _i, _l, _i, _i, _p],
     "mi_gn_bwd": [_p, _i, _p, _i, _i, _l, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _l, _p],
     "mi_conv_plan_create": [C.POINTER(_p), _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
+    "mi_upconv_plan_create": [C.POINTER(_p), _i, _i, _i, _i, _i, _i],
     "mi_conv_plan_destroy": [_p],
     "mi_conv_plan_out_dims": [_p, C.POINTER(_i)],
     "mi_conv_pack_weights": [_p, _p, _p],
@@ -91,7 +92,7 @@ _lib = None
 # Version of the C ABI this binding was written against (csrc/api.hip: mi_abi_version).  Entry points have changed their argument
 # lists under unchanged names between versions, and *.so files are not tracked by git: a stale library (or an MI_LIB_PATH pointing at
 # an old ablation build) resolves every symbol and then reads shifted arguments.  load() refuses it.
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def exported_symbols() -> list[str]:

@@ -178,8 +178,7 @@ class AutoencoderKL(HipModule):
             elif kind == "norm":  # GroupNorm directly followed by a conv, no activation (AEKL:450-463, 604-615)
                 pending_norm = E.gn(c, x, name, self.groups, self.eps)
             elif kind == "up":
-                x = E.upsample(c, x, step[2])
-                x = E.conv(c, x, name + ".conv.conv", self._k3, self._s1, self._p1)
+                x = E.upsample_conv(c, x, name + ".conv.conv", step[2], self._k3, self._p1)
             first = False
         return x
 

@@ -157,9 +157,10 @@ class Upsample(_Block):
 
         def runner(c, xin, need_dx):
             x_cl = ops.to_channels_last(xin.contiguous().float())
-            y = E.upsample(c, x_cl, self._s)
             if self.use_conv:
-                y = E.conv(c, y, "conv.conv", k3, (1, 1, 1), self._p)
+                y = E.upsample_conv(c, x_cl, "conv.conv", self._s, k3, self._p)
+            else:
+                y = E.upsample(c, x_cl, self._s)
             return (y,), {"x_cl": x_cl}
 
         return self._edge(runner, x)

@@ -1435,8 +1435,23 @@ Geom make_geom(int VB, int Do, int Ho, int Wo, const int halo[3], int N, int vox
 
 }  // namespace
 
+// One direction of a factor-2 layer on the phase kernels of convph.hip
+struct PhaseSide {
+  int mode = 0;            // 1 scatter / 2 gather; 0: this direction does not run there
+  int ncb = 1, ny = 0, nchunks = 0, nfrags = 0;
+  int Ko = 0, Ki = 0;      // kernel output / input channels
+  int tr = 0;              // kernel-out = torch-in (data gradients)
+  Geom g;                  // tile grid = the coarse side
+  u32x4* d_w = nullptr;    // packed fragments [cout group][phase][chunk][tap][k-step][cout block]
+  unsigned* d_masks = nullptr;  // [phase * 8 + tap] -> bit k set: torch tap k is summed into this fragment
+};
+
 struct mi_conv_plan {
   int N, Di, Hi, Wi, Cin, Cout, k[3], s[3], p[3];
+  bool up = false;         // nearest x2 interpolation in front of the k3 s1 p1 conv (mi_upconv_plan_create): Di.. coarse, Do.. = 2 Di..
+  PhaseSide ph_fwd, ph_dg;
+  mi_conv_plan* up_inner = nullptr;  // upconv: plain k3 s1 p1 plan on the fine grid (weight gradient; fallback)
+  bf16* d_xup = nullptr;   // upconv: nearest-upsampled x for up_inner
   int Do, Ho, Wo;
   int f[3], Q;            // space-to-depth factors of x for strided axes
   int Dp, Hp, Wp;         // depth-side dims of x (== Do.. for supported (k,s,p))
@@ -1615,6 +1630,76 @@ int launch_igemm_any(const ConvArgs& a, int NCB, int mode, int ntiles, int ny, h
   return launch_igemm<1, 2, 4, 2, 0>(a, ntiles, ny, st);
 }
 
+// ---- phase convolutions (convph.hip) -----------------------------------------------------------------------------------------------
+enum PhaseKind { UC_FWD, UC_DG, S2_FWD, S2_DG };
+// torch taps (bit k of 3) summed into box tap t of phase / class b along one axis (derivations: convph.hip)
+unsigned axis_set(PhaseKind kind, int b, int t) {
+  static const unsigned S[2][2] = {{1u, 6u}, {3u, 4u}};  // S(0,0) = {0}, S(0,1) = {1,2}, S(1,0) = {0,1}, S(1,1) = {2}
+  switch (kind) {
+    case UC_FWD: return S[b][t];
+    case UC_DG: return S[b][1 - t];
+    case S2_FWD: return b ? (t ? 4u : 1u) : (t ? 0u : 2u);
+    case S2_DG: return b ? (t ? 1u : 4u) : (t ? 2u : 0u);
+  }
+  return 0u;
+}
+int phase_side_create(PhaseSide& ps, PhaseKind kind, int mode, int tr, int Ko, int Ki, int gd, int gh, int gw, int N) {
+  const int halo[3] = {1, 1, 1};
+  ps.g = make_geom(2, gd, gh, gw, halo, N);
+  if (ps.g.TD != 4 || ps.g.TH != 8 || ps.g.TW != 8) return MI_ERR_UNSUPPORTED;
+  ps.Ko = Ko; ps.Ki = Ki; ps.tr = tr;
+  ps.ncb = Ko > 32 ? 2 : 1;
+  const int64_t tiles = (int64_t)N * ps.g.tilesD * ps.g.tilesH * ps.g.tilesW;
+  if (tiles * ((Ko + 63) / 64) <= 128) ps.ncb = 1;  // few tiles: 32 output channels per workgroup fill more CUs
+  ps.ny = (Ko + 32 * ps.ncb - 1) / (32 * ps.ncb);
+  ps.nchunks = (Ki + 31) / 32;
+  ps.nfrags = ps.ny * 8 * ps.nchunks * 8 * 2 * ps.ncb;
+  unsigned masks[64];
+  for (int pc = 0; pc < 8; ++pc)
+    for (int t = 0; t < 8; ++t) {
+      const unsigned sd = axis_set(kind, (pc >> 2) & 1, (t >> 2) & 1), sh = axis_set(kind, (pc >> 1) & 1, (t >> 1) & 1), sw = axis_set(kind, pc & 1, t & 1);
+      unsigned m = 0;
+      for (int kd = 0; kd < 3; ++kd)
+        for (int kh = 0; kh < 3; ++kh)
+          for (int kw = 0; kw < 3; ++kw)
+            if (((sd >> kd) & 1) && ((sh >> kh) & 1) && ((sw >> kw) & 1)) m |= 1u << ((kd * 3 + kh) * 3 + kw);
+      masks[pc * 8 + t] = m;
+    }
+  if (hipMalloc((void**)&ps.d_masks, sizeof(masks)) != hipSuccess) return (int)hipErrorOutOfMemory;
+  if (hipMemcpy(ps.d_masks, masks, sizeof(masks), hipMemcpyHostToDevice) != hipSuccess) return (int)hipErrorUnknown;
+  if (hipMalloc((void**)&ps.d_w, (size_t)ps.nfrags * 1024) != hipSuccess) return (int)hipErrorOutOfMemory;
+  ps.mode = mode;
+  return 0;
+}
+void phase_side_free(PhaseSide& ps) {
+  if (ps.d_w) (void)hipFree(ps.d_w);
+  if (ps.d_masks) (void)hipFree(ps.d_masks);
+  ps.d_w = nullptr; ps.d_masks = nullptr; ps.mode = 0;
+}
+int phase_side_pack(const PhaseSide& ps, const float* w, int Co_t, int Ci_t, hipStream_t st) {
+  if (!ps.mode) return 0;
+  return mi_launch_pack_phase(w, ps.d_w, ps.d_masks, ps.nfrags, ps.ncb, ps.nchunks, ps.Ko, ps.Ki, Co_t, Ci_t, ps.tr, st);
+}
+// x: kernel input [N][id][ih][iw] with pitch x_cs, y: kernel output [N][od][oh][ow] with pitch y_cs (one of the two grids is twice the other)
+int phase_side_run(const PhaseSide& ps, const void* x, int x_cs, int id, int ih, int iw, void* y, int y_cs, int od, int oh, int ow, int N,
+                   const float* addvec, int addvec_stride, hipStream_t st) {
+  if (!ps.mode || (x_cs & 7) || (y_cs & 7)) return MI_ERR_UNSUPPORTED;
+  const int64_t xb = (int64_t)N * id * ih * iw * x_cs * 2, yb = (int64_t)N * od * oh * ow * y_cs * 2;
+  if (xb >= (1ll << 32) || yb >= (1ll << 32) || (int64_t)ps.nfrags * 1024 >= (1ll << 32)) return MI_ERR_UNSUPPORTED;
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = (const bf16*)x; a.x_cs = x_cs; a.N = N; a.Di = id; a.Hi = ih; a.Wi = iw; a.Cin = ps.Ki;
+  a.y = (bf16*)y; a.y_cs = y_cs; a.Cout = ps.Ko; a.Do = od; a.Ho = oh; a.Wo = ow;
+  a.ogpq = ps.ny; a.outc_q = ps.Ko;
+  a.wpk = ps.d_w; a.wpk_bytes = (unsigned)ps.nfrags * 1024u; a.nchunks = ps.nchunks;
+  a.addvec = addvec; a.addvec_stride = addvec_stride;
+  a.x_bytes = (unsigned)xb; a.y_bytes = (unsigned)yb;
+  a.perm16 = 1;
+  a.g = ps.g;
+  const int ntiles = N * a.g.tilesD * a.g.tilesH * a.g.tilesW;
+  return mi_launch_convph(a, ps.ncb, ps.mode, ntiles, ps.ny, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1725,6 +1810,16 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   if ((e = upload(P->wg_pair_off, &P->d_pair_off)) || (e = upload(P->wg_uitems, &P->d_uitems))) { mi_conv_plan_destroy(P); return e; }
   if (hipMalloc((void**)&P->d_part, (size_t)nsplit * off * 4) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
   if (hipMalloc((void**)&P->d_cspart, (size_t)nsplit * N * Cout * 4) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
+  {  // k3 s2 p1 on all three axes: forward and data gradient on the phase kernels (no space-to-depth copies of x / dx)
+    static const int use_ph = env_int("MI_CONVPH", 1);
+    bool s2all = Di > 1;
+    for (int a = 0; a < 3; ++a) s2all = s2all && k[a] == 3 && s[a] == 2 && p[a] == 1;
+    if (use_ph && s2all && (Cin % 8) == 0 && (Cout % 8) == 0) {
+      int e1 = phase_side_create(P->ph_fwd, S2_FWD, 2, 0, Cout, Cin, P->Do, P->Ho, P->Wo, N);
+      int e2 = e1 ? e1 : phase_side_create(P->ph_dg, S2_DG, 1, 1, Cin, Cout, P->Do, P->Ho, P->Wo, N);
+      if (e1 || e2) { phase_side_free(P->ph_fwd); phase_side_free(P->ph_dg); if ((e1 ? e1 : e2) != MI_ERR_UNSUPPORTED) { mi_conv_plan_destroy(P); return e1 ? e1 : e2; } }
+    }
+  }
   if (P->strided) {
     size_t nb = (size_t)N * P->Dp * P->Hp * P->Wp * P->Q * Cin * 2;
     if (hipMalloc((void**)&P->d_xs, nb) != hipSuccess || hipMalloc((void**)&P->d_dxs, nb) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
@@ -1735,6 +1830,9 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
 
 int mi_conv_plan_destroy(mi_conv_plan* P) {
   if (!P) return 0;
+  phase_side_free(P->ph_fwd); phase_side_free(P->ph_dg);
+  if (P->up_inner) mi_conv_plan_destroy(P->up_inner);
+  if (P->d_xup) (void)hipFree(P->d_xup);
   free_tables(P->fwd); free_tables(P->dg); free_tables(P->wg);
   if (P->d_pair_off) (void)hipFree(P->d_pair_off);
   if (P->d_uitems) (void)hipFree(P->d_uitems);
@@ -1748,6 +1846,32 @@ int mi_conv_plan_destroy(mi_conv_plan* P) {
   return 0;
 }
 
+// Upsample.forward of the reference (UNet:569-588 / AEKL Upsample): nearest x2 interpolation on all three axes, then the k3 s1 p1
+// `Convolution`.  x: [N][D][H][W][Cin] coarse, y: [N][2D][2H][2W][Cout].  The plan answers mi_conv_fwd / mi_conv_dgrad / mi_conv_wgrad /
+// mi_conv_pack_weights like any other (weights: the conv's torch tensor [Cout][Cin][3][3][3]).
+int mi_upconv_plan_create(mi_conv_plan** out, int N, int D, int H, int W, int Cin, int Cout) {
+  if (!out || N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return MI_ERR_BAD_ARG;
+  if (D == 1) return MI_ERR_UNSUPPORTED;  // 2-D nets: upsample kernel + plain conv (engine.upsample)
+  mi_conv_plan* P = new mi_conv_plan();
+  P->up = true;
+  P->N = N; P->Di = D; P->Hi = H; P->Wi = W; P->Cin = Cin; P->Cout = Cout;
+  P->Do = 2 * D; P->Ho = 2 * H; P->Wo = 2 * W;
+  for (int a = 0; a < 3; ++a) { P->k[a] = 3; P->s[a] = 1; P->p[a] = 1; P->f[a] = 1; }
+  P->Q = 1; P->KT = 27; P->Dp = D; P->Hp = H; P->Wp = W;
+  const int k3[3] = {3, 3, 3}, s1[3] = {1, 1, 1}, p1[3] = {1, 1, 1};
+  int e = mi_conv_plan_create(&P->up_inner, N, 2 * D, 2 * H, 2 * W, Cin, Cout, k3, s1, p1);
+  if (e) { P->up_inner = nullptr; mi_conv_plan_destroy(P); return e; }
+  if (hipMalloc((void**)&P->d_xup, (size_t)N * 8 * D * H * W * Cin * 2) != hipSuccess) { mi_conv_plan_destroy(P); return (int)hipErrorOutOfMemory; }
+  static const int use_ph = env_int("MI_CONVPH", 1);
+  if (use_ph && (Cin % 8) == 0 && (Cout % 8) == 0) {
+    int e1 = phase_side_create(P->ph_fwd, UC_FWD, 1, 0, Cout, Cin, D, H, W, N);
+    int e2 = e1 ? e1 : phase_side_create(P->ph_dg, UC_DG, 2, 1, Cin, Cout, D, H, W, N);
+    if (e1 || e2) { phase_side_free(P->ph_fwd); phase_side_free(P->ph_dg); if ((e1 ? e1 : e2) != MI_ERR_UNSUPPORTED) { mi_conv_plan_destroy(P); return e1 ? e1 : e2; } }
+  }
+  *out = P;
+  return 0;
+}
+
 int mi_conv_plan_out_dims(const mi_conv_plan* P, int* dims3) {
   if (!P || !dims3) return MI_ERR_BAD_ARG;
   dims3[0] = P->Do; dims3[1] = P->Ho; dims3[2] = P->Wo;
@@ -1757,6 +1881,12 @@ int mi_conv_plan_out_dims(const mi_conv_plan* P, int* dims3) {
 // fp32 master weight [Cout][Cin][kd][kh][kw] -> packed bf16 fragments for forward and dgrad
 int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
   if (!P || !w) return MI_ERR_BAD_ARG;
+  {
+    int e = phase_side_pack(P->ph_fwd, w, P->Cout, P->Cin, st);
+    if (!e) e = phase_side_pack(P->ph_dg, w, P->Cout, P->Cin, st);
+    if (e) return e;
+    if (P->up) return mi_conv_pack_weights(P->up_inner, w, st);
+  }
   hipLaunchKernelGGL(k_pack_weights, dim3(((P->fwd.nfrags + P->dg.nfrags) * 64 + 255) / 256), dim3(256), 0, st, w, P->fwd.d_wpk,
                      P->fwd.d_items, P->fwd.nfrags, P->dg.d_wpk, P->dg.d_items, P->dg.nfrags, P->Cout, P->Cin, P->KT, P->d_c1w,
                      P->d_c1w ? 27 * P->Cin * P->Cout : 0);
@@ -1765,11 +1895,13 @@ int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
   return 0;
 }
 
+struct PhaseJob { const PhaseSide* side; const float* w; int Co_t, Ci_t; };
 struct mi_pack_batch {
   PackGroup* d_groups = nullptr;
   int2* d_gtaps = nullptr;
   int ngroups = 0;
   size_t lds = 0;
+  std::vector<PhaseJob> phase;  // phase-kernel sides of the batch's plans: one small launch each (a handful per network)
 };
 namespace {
 // groups of one fragment table: fragments keyed by (co0, ci0) in order of first appearance
@@ -1809,9 +1941,13 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
   std::vector<PackGroup> groups;
   std::vector<int2> gtaps;
   size_t lds = 0;
+  std::vector<PhaseJob> phase;
   for (int i = 0; i < n; ++i) {
     mi_conv_plan* P = plans[i];
     if (!P || !weights[i]) return MI_ERR_BAD_ARG;
+    if (P->ph_fwd.mode) phase.push_back(PhaseJob{&P->ph_fwd, weights[i], P->Cout, P->Cin});
+    if (P->ph_dg.mode) phase.push_back(PhaseJob{&P->ph_dg, weights[i], P->Cout, P->Cin});
+    if (P->up) P = P->up_inner;  // (its tables pack like any k3 s1 conv's)
     P->c1_packed = true;
     const size_t g0 = groups.size();
     add_groups(groups, gtaps, P->fwd, weights[i], P);
@@ -1824,6 +1960,7 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
   if (lds > 64 * 1024) return MI_ERR_UNSUPPORTED;
   mi_pack_batch* B = new mi_pack_batch();
   B->ngroups = (int)groups.size(); B->lds = lds;
+  B->phase = phase;
   if (hipMalloc((void**)&B->d_groups, sizeof(PackGroup) * (groups.size() ? groups.size() : 1)) != hipSuccess ||
       hipMalloc((void**)&B->d_gtaps, sizeof(int2) * (gtaps.size() ? gtaps.size() : 1)) != hipSuccess) {
     mi_conv_pack_batch_destroy(B);
@@ -1839,6 +1976,10 @@ int mi_conv_pack_batch_run(mi_pack_batch* B, hipStream_t st) {
   if (!B) return MI_ERR_BAD_ARG;
   if (B->ngroups) hipLaunchKernelGGL(k_pack_groups, dim3(B->ngroups), dim3(256), B->lds, st, B->d_groups, B->d_gtaps);
   MI_CHECK_LAUNCH();
+  for (const PhaseJob& j : B->phase) {
+    const int e = phase_side_pack(*j.side, j.w, j.Co_t, j.Ci_t, st);
+    if (e) return e;
+  }
   return 0;
 }
 int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
@@ -1850,7 +1991,7 @@ int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
 }
 
 int mi_conv_fwd_stats_chunks(const mi_conv_plan* P) {
-  if (!P || !P->v27_fwd || P->N > 16 || P->ncb_fwd != 1) return 0;
+  if (!P || P->up || !P->v27_fwd || P->N > 16 || P->ncb_fwd != 1) return 0;
   return 4 * mi_conv27_grid_x(P->N * P->g_fwd.tilesD * P->g_fwd.tilesH * P->g_fwd.tilesW, P->fwd.ny);
 }
 
@@ -1858,6 +1999,16 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
                 const void* res, int res_cs, void* y, int y_cs, float* out_stats, hipStream_t st) {
   if (!P || !x || !y || x_cs < P->Cin || y_cs < P->Cout) return MI_ERR_BAD_ARG;
   if (out_stats && (!mi_conv_fwd_stats_chunks(P) || scale_shift || (x_cs & 7))) return MI_ERR_UNSUPPORTED;  // only the conv27 path emits them
+  if (P->ph_fwd.mode && !scale_shift && !res) {  // Upsample + conv (scatter) / k3 s2 conv (gather) on the phase kernels
+    const int e = phase_side_run(P->ph_fwd, x, x_cs, P->Di, P->Hi, P->Wi, y, y_cs, P->Do, P->Ho, P->Wo, P->N, addvec, addvec_stride, st);
+    if (e != MI_ERR_UNSUPPORTED) return e;
+  }
+  if (P->up) {  // fallback: materialise the nearest-upsampled tensor, plain k3 s1 conv on the fine grid
+    if (x_cs != P->Cin) return MI_ERR_UNSUPPORTED;
+    int e = mi_upsample_nearest_fwd(x, P->d_xup, P->N, P->Di, P->Hi, P->Wi, P->Cin, 2, 2, 2, st);
+    if (e) return e;
+    return mi_conv_fwd(P->up_inner, P->d_xup, P->Cin, scale_shift, silu, addvec, addvec_stride, res, res_cs, y, y_cs, nullptr, st);
+  }
   if ((P->c1_in || P->c1_out) && P->c1_packed && !scale_shift && !res) {
     int e = P->c1_in ? mi_launch_c1_expand(x, x_cs, P->d_c1w, addvec, addvec_stride, y, y_cs, P->N, P->Di, P->Hi, P->Wi, P->Cout, 0, st)
                      : mi_launch_c1_reduce(x, x_cs, P->d_c1w, addvec, addvec_stride, y, y_cs, P->N, P->Di, P->Hi, P->Wi, P->Cin, st);
@@ -1911,6 +2062,16 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
 
 int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_cs, hipStream_t st) {
   if (!P || !dy || !dx || dy_cs < P->Cout || dx_cs < P->Cin) return MI_ERR_BAD_ARG;
+  if (P->ph_dg.mode) {  // data gradient of Upsample + conv (gather from the fine dy) / of the k3 s2 conv (scatter into the fine dx)
+    const int e = phase_side_run(P->ph_dg, dy, dy_cs, P->Do, P->Ho, P->Wo, dx, dx_cs, P->Di, P->Hi, P->Wi, P->N, nullptr, 0, st);
+    if (e != MI_ERR_UNSUPPORTED) return e;
+  }
+  if (P->up) {  // fallback: data gradient on the fine grid, then fold the 2x2x2 blocks (nearest-upsample backward)
+    if (dx_cs != P->Cin) return MI_ERR_UNSUPPORTED;
+    int e = mi_conv_dgrad(P->up_inner, dy, dy_cs, P->d_xup, P->Cin, st);
+    if (e) return e;
+    return mi_upsample_nearest_bwd(P->d_xup, dx, P->N, P->Di, P->Hi, P->Wi, P->Cin, 2, 2, 2, st);
+  }
   if (P->c1_out && P->c1_packed) {  // dx[v][ci] = sum_t dy[v - t] W[0][ci][t]: the 1 -> C kernel with the taps flipped
     int e = mi_launch_c1_expand(dy, dy_cs, P->d_c1w, nullptr, 0, dx, dx_cs, P->N, P->Di, P->Hi, P->Wi, P->Cin, 1, st);
     if (e != MI_ERR_UNSUPPORTED) return e;
@@ -1959,6 +2120,12 @@ int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_c
 int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const void* dy, int dy_cs, float* dw,
                   float* dy_colsum, int dy_colsum_stride, hipStream_t st) {
   if (!P || !x || !dy || !dw || x_cs < P->Cin || dy_cs < P->Cout) return MI_ERR_BAD_ARG;
+  if (P->up) {  // weight gradient of Upsample + conv: on the fine grid against the nearest-upsampled x
+    if (x_cs != P->Cin || scale_shift) return MI_ERR_UNSUPPORTED;
+    int e = mi_upsample_nearest_fwd(x, P->d_xup, P->N, P->Di, P->Hi, P->Wi, P->Cin, 2, 2, 2, st);
+    if (e) return e;
+    return mi_conv_wgrad(P->up_inner, P->d_xup, P->Cin, nullptr, 0, dy, dy_cs, dw, dy_colsum, dy_colsum_stride, st);
+  }
   static const int use_w11 = env_int("MI_WGRAD1X1", 1);
   if (use_w11 && P->KT == 1 && !P->strided && !scale_shift && !(dy_colsum && dy_colsum_stride != 0 && dy_colsum_stride < P->Cout)) {
     int e = mi_launch_wgrad1x1(x, x_cs, P->Cin, dy, dy_cs, P->Cout, P->N, (int64_t)P->Di * P->Hi * P->Wi, dw, dy_colsum, dy_colsum_stride, st);

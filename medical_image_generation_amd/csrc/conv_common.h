@@ -124,6 +124,11 @@ using namespace mi_conv;
 // conv27.hip: k3 s1 p1 3-D forward (flip = 0) / data gradient (flip = 1) on the 4x8x8 tile; a.g / tables as for the table-driven kernel
 int mi_launch_conv27(const ConvArgs& a, int NCB, int flip, int ntiles, int ny, hipStream_t st);
 int mi_conv27_grid_x(int ntiles, int ny);  // gridDim.x of that launch (4 statistics chunks per workgroup)
+// convph.hip: factor-2 phase convolutions (mode 1 scatter: tile grid = coarse input, fine output; mode 2 gather: fine input, tile grid =
+// coarse output) and their weight pack (fragment = fp32 sum of the master weights over a tap set, d_masks[phase * 8 + tap])
+int mi_launch_convph(const ConvArgs& a, int NCB, int mode, int ntiles, int ny, hipStream_t st);
+int mi_launch_pack_phase(const float* w, void* out, const unsigned* d_masks, int nfrags, int NCB, int nchunks, int Ko, int Ki, int Co_t, int Ci_t,
+                         int tr, hipStream_t st);
 // conv1x1.hip: 1x1x1 forward / data gradient as a streaming GEMM over voxels
 int mi_launch_conv1x1(const ConvArgs& a, int NCB, int ny, hipStream_t st);
 int mi_launch_wgrad1x1(const void* x, int x_cs, int Cin, const void* dy, int dy_cs, int Cout, int N, int64_t V, float* dw, float* colsum,

@@ -224,8 +224,24 @@ def gn(ctx: Ctx, x, name, groups, eps):
     return st
 
 
+# Upsample (nearest x2 on all three axes) + k3 p1 conv as ONE op on the phase kernels (csrc/convph.hip: 8 taps per output voxel on
+# the coarse tensor instead of 27 on an up-sampled copy); MI_UPCONV=0: upsample kernel, then the plain conv (A/B runs).
+UPCONV = _os.environ.get("MI_UPCONV", "1") == "1"
+
+
+def upsample_conv(ctx: Ctx, x, name, factors, kernel, padding, out=None):
+    """Upsample.forward (UNet:569-588, AEKL Upsample): F.interpolate(x, scale_factor=factors, mode="nearest") then the stride-1 conv
+    `name` (kernel, padding).  Fused when the layer is the 3-D factor-2 / k3 / padding-1 case every planner-generated config has."""
+    n, d, h, w, cin = x.shape
+    fused = UPCONV and tuple(factors) == (2, 2, 2) and tuple(kernel) == (3, 3, 3) and tuple(padding) == (1, 1, 1) and d > 1 and \
+        cin % 8 == 0 and ctx.p(name + ".weight").shape[0] % 8 == 0 and x.is_contiguous()
+    if not fused:
+        return conv(ctx, upsample(ctx, x, factors), name, kernel, (1, 1, 1), padding, out=out)
+    return conv(ctx, x, name, kernel, (1, 1, 1), padding, out=out, upconv=True)
+
+
 def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addvec=None, res=None, d_addvec=None,
-         need_dx=True, bias_grad_like=None, out=None):
+         need_dx=True, bias_grad_like=None, out=None, upconv=False):
     """y = conv(act(x)) + addvec + res   (weight `name.weight`, bias folded into addvec by the caller or taken from
     `name.bias` when addvec is None).  norm: GNStats of x for the fused prologue.  d_addvec: fp32 [N, Cout] view that
     receives the per-sample column sums of dy (time-embedding gradient) in backward.  bias_grad_like: name of a conv whose
@@ -237,7 +253,7 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
     key = (name, n, d, h, w)
     plan = ctx.plans.get(key)
     if plan is None:
-        plan = ctx.plans[key] = ops.ConvPlan(n, (d, h, w), cin, cout, kernel, stride, padding)
+        plan = ctx.plans[key] = ops.UpConvPlan(n, (d, h, w), cin, cout) if upconv else ops.ConvPlan(n, (d, h, w), cin, cout, kernel, stride, padding)
     if key not in ctx.packed:
         plan.pack(wt)  # [Cout, Cin, (kd,) kh, kw] contiguous: same memory layout for 2-D and 3-D nets
         ctx.packed.add(key)

@@ -271,6 +271,20 @@ class ConvPlan:
              ptr(dweight_f32), ptr(colsum), cs_stride)
 
 
+class UpConvPlan(ConvPlan):
+    """Upsample.forward as one op (mi_upconv_plan_create): nearest x2 on all three axes, then the k3 s1 p1 conv; x is the COARSE
+    tensor [N, D, H, W, Cin], y [N, 2D, 2H, 2W, Cout].  Same methods as ConvPlan (dgrad returns the coarse dx)."""
+
+    def __init__(self, n, dims, cin, cout):
+        self.n, self.dims, self.cin, self.cout = n, tuple(dims), cin, cout
+        self.kernel, self.stride, self.padding = (3, 3, 3), (1, 1, 1), (1, 1, 1)
+        h = C.c_void_p()
+        _lib.call_raw("mi_upconv_plan_create", C.byref(h), n, dims[0], dims[1], dims[2], cin, cout)
+        self.handle = h
+        self.out_dims = tuple(2 * d for d in dims)
+        self.stats_chunks = 0
+
+
 def colsum(x, out=None, accumulate=False, merge_batch=False):
     """out[n, c] (+)= sum over voxels; `out` may be a column slice of a wider fp32 matrix.  merge_batch: sum over n too."""
     n, v, c = _vox(x)

@@ -521,9 +521,8 @@ class DiffusionModelUNet(HipModule):
                 pending, view = cat_buffer(rch[i])
                 h = self._resnet(c, h, f"up_blocks.{i}.upsampler", temb_all, d_temb_all, out=view, mode="up", stride=rs[i])
             elif i != L - 1:  # Upsample.forward (UNet:569-588): nearest x stride, then k3 conv with the LEVEL's padding
-                h = E.upsample(c, h, rs[i])
                 pending, view = cat_buffer(rch[i])
-                h = E.conv(c, h, f"up_blocks.{i}.upsampler.conv.conv", k3, (1, 1, 1), rp[i], out=view)
+                h = E.upsample_conv(c, h, f"up_blocks.{i}.upsampler.conv.conv", rs[i], k3, rp[i], out=view)
         no = E.gn(c, h, "out.0", self.groups, self.eps)
         p1 = (0,) * (3 - sd) + (1,) * sd
         return E.conv(c, h, "out.2.conv", k3, (1, 1, 1), p1, norm=no, silu=True)

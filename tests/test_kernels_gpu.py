@@ -153,6 +153,12 @@ CONV_CASES = [
     (2, 32, 32, (8, 8, 8), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (1, 64, 64, (6, 10, 12), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (1, 32, 32, (8, 8, 4), (3, 3, 1), (2, 2, 1), (1, 1, 0)),
+    # k3 s2 p1 on all three axes = the phase kernels (convph.hip): odd extents (the last output reads a padded input voxel), 3 input
+    # chunks, 32 / 64 / 128 output channels, 2 images, a tile grid with ragged tiles in every axis
+    (2, 96, 64, (7, 9, 11), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (1, 64, 32, (10, 18, 34), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (1, 128, 128, (16, 16, 16), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
+    (2, 32, 32, (24, 40, 36), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (2, 32, 64, (1, 16, 16), (1, 3, 3), (1, 1, 1), (0, 1, 1)),
     (1, 64, 64, (1, 20, 12), (1, 3, 3), (1, 2, 2), (0, 1, 1)),
     (1, 16, 48, (4, 6, 6), (3, 3, 3), (1, 1, 1), (1, 1, 1)),
@@ -189,6 +195,59 @@ def test_conv_fwd_dgrad_wgrad(ops, case):
     plan.wgrad(xc, gc, dw2, colsum=cb)
     check(cb.cpu() - 1, g.sum(dim=(0, 2, 3, 4)), 1e-2, "fused bias gradient")
     check(dw2.cpu() - 1, wr.grad, 1e-2, "conv wgrad (batch-summed bias gradient variant)")
+
+
+UPCONV_CASES = [
+    # (N, Cin, Cout, coarse dims): one / two / three / four input chunks (two chunks: the halo image of a tile serves all 8 phases),
+    # 32 / 64 / 128 output channels, ragged coarse tile grids, 2 images
+    (1, 64, 64, (8, 8, 8)),
+    (2, 32, 32, (4, 8, 8)),
+    (1, 64, 64, (5, 9, 11)),
+    (2, 96, 64, (6, 10, 12)),
+    (1, 128, 128, (8, 16, 16)),
+    (1, 32, 64, (3, 5, 7)),
+    (1, 64, 32, (12, 20, 24)),
+    (1, 64, 64, (16, 32, 32)),   # 128 coarse tiles: several tiles per workgroup, the 64-channel variant
+]
+
+
+@pytest.mark.parametrize("case", UPCONV_CASES, ids=lambda c: f"n{c[0]}_{c[1]}to{c[2]}_{'x'.join(map(str, c[3]))}")
+def test_upsample_conv_fwd_dgrad_wgrad(ops, case):
+    """Upsample.forward (UNet:569-588) as one op -- nearest x2 + k3 s1 p1 conv by 8 phase convolutions on the coarse tensor -- against
+    F.interpolate(mode="nearest") + F.conv3d autograd in fp32 on the bf16-rounded inputs.  The phase weights are sums of up to 8 taps
+    rounded to bf16 once, the reference multiplies the taps one by one: both are within bf16 rounding of the exact result."""
+    n, cin, cout, dims = case
+    x = rnd(n, cin, *dims)
+    w = rnd(cout, cin, 3, 3, 3, scale=1.0 / math.sqrt(cin * 27))
+    bias = rnd(cout, seed=3)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = F.conv3d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), wr, bias, padding=1)
+    g = rnd(*y.shape, seed=4)
+    y.backward(g)
+    plan = ops.UpConvPlan(n, dims, cin, cout)
+    assert plan.out_dims == tuple(y.shape[2:])
+    plan.pack(w.to(dev))
+    xc, gc = cl(x), cl(g)
+    check(cf(plan.fwd(xc, addvec=bias.to(dev))), y.detach(), 1e-2, "upsample + conv fwd")
+    # into a channel-slice view of a wider buffer (how the U-Net's up path receives it: the first channels of a concat buffer)
+    wide = torch.zeros((n,) + plan.out_dims + (cout + 32,), dtype=torch.bfloat16, device=dev)
+    plan.fwd(xc, addvec=bias.to(dev), out=wide[..., :cout])
+    check(cf(wide[..., :cout].contiguous()), y.detach(), 1e-2, "upsample + conv fwd into a concat slot")
+    assert float(wide[..., cout:].abs().max()) == 0
+    check(cf(plan.dgrad(gc)), xr.grad, 1e-2, "upsample + conv dgrad (coarse dx)")
+    check(cf(plan.dgrad(wide_view(gc))), xr.grad, 1e-2, "upsample + conv dgrad from a strided dy view")
+    dw = torch.ones_like(w).to(dev)  # wgrad accumulates
+    cb = torch.ones(cout, device=dev)
+    plan.wgrad(xc, gc, dw, colsum=cb)
+    check(dw.cpu() - 1, wr.grad, 1e-2, "upsample + conv wgrad")
+    check(cb.cpu() - 1, g.sum(dim=(0, 2, 3, 4)), 1e-2, "upsample + conv bias gradient")
+
+
+def wide_view(t):
+    """t [N, D, H, W, C] as the LAST C channels of a buffer with 32 more channels (a d(concat) slice)."""
+    buf = torch.zeros(t.shape[:-1] + (t.shape[-1] + 32,), dtype=t.dtype, device=t.device)
+    buf[..., 32:] = t
+    return buf[..., 32:]
 
 
 @pytest.mark.parametrize("n,cin,cout,dims,groups", [(2, 32, 32, (8, 8, 8), 32), (1, 64, 96, (5, 9, 11), 32), (1, 32, 64, (8, 16, 16), 16),
