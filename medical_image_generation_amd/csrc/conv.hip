@@ -435,6 +435,11 @@ struct WgradArgs {
   int dbg;              // ablation knob (MI_WGRAD_DBG): 1 = stage only the first tile, 2 = skip the MFMA loop
   float* colsum;        // optional: colsum[n * colsum_stride + co] += sum over voxels of dy (bias / time-embedding gradient)
   int colsum_stride;
+  // LDS-DMA kernel, factor-2 layers read in place (no space-to-depth / up-sampled copy in HBM): image voxel u of a pair is tensor voxel
+  // sx * u + class (x image; k3 s2 conv: sx = 2) resp. sy * u + phase (dY image; Upsample + conv: sy = 2), the class / phase of the
+  // pair = bits 2..0 (d, h, w) of its header word 3.  1 / 1: dense images.
+  int sx, sy;
+  int cs_chunks;        // the first cs_chunks chunk slots of a cout block own the dY column sums (1; Upsample + conv: its 8 phases)
 };
 
 // ds_read_b64_tr_b16 (4 voxels x 16 channels delivered channel-per-lane) issued through asm so that a whole k-step's
@@ -822,7 +827,7 @@ struct DmaPieces {
 
 // x halo image: piece i (1 KiB) -> halo voxels 16 i .. 16 i + 15, lane -> voxel 16 i + (lane >> 2), 16-byte part lane & 3
 template <int MAXP>
-__device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane, int Hi, int Wi, int cs) {
+__device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane, int Hi, int Wi, int cs, int sx = 1) {
   const int hvox = g.HD * g.HH * g.HW;
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
@@ -830,18 +835,20 @@ __device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, in
     const int v = i * 16 + (lane >> 2);
     const int hd = v / (g.HH * g.HW), rem = v - hd * (g.HH * g.HW), hh = rem / g.HW, hw = rem - hh * g.HW;
     d.pk[k] = (i < npieces && v < hvox) ? ((hd << 20) | (hh << 10) | hw) : -1;
-    d.off[k] = (i < npieces && v < hvox) ? (unsigned)(((hd * Hi + hh) * Wi + hw) * cs + (lane & 3) * 8) * 2u : 0u;
+    d.off[k] = (i < npieces && v < hvox) ? (unsigned)(((sx * hd * Hi + sx * hh) * Wi + sx * hw) * cs + (lane & 3) * 8) * 2u : 0u;
   }
 }
+// sx, cls: image voxel u = tensor voxel sx * u + (cls bit 2 / 1 / 0 along d / h / w) (WgradArgs::sx)
 template <int MAXP>
 __device__ __forceinline__ void dma_issue_x(const DmaPieces<MAXP>& d, const ConvArgs& a, char* dst, int first, int stride, int npieces, int lane,
-                                            int n, int d0, int h0, int w0, int src_c0, bool valid = true) {
+                                            int n, int d0, int h0, int w0, int src_c0, bool valid = true, int sx = 1, int cls = 0) {
   const Geom& g = a.g;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
   const int c = src_c0 + (lane & 3) * 8;
-  const int od = d0 - g.hd, oh = h0 - g.hh, ow = w0 - g.hw;
+  const int od = sx * (d0 - g.hd) + ((cls >> 2) & 1), oh = sx * (h0 - g.hh) + ((cls >> 1) & 1), ow = sx * (w0 - g.hw) + (cls & 1);
   const unsigned base = (unsigned)((((n * a.Di + od) * a.Hi + oh) * a.Wi + ow) * a.x_cs + src_c0) * 2u;  // scalar (mod 2^32)
-  const bool interior = valid & (od >= 0) & (od + g.HD <= a.Di) & (oh >= 0) & (oh + g.HH <= a.Hi) & (ow >= 0) & (ow + g.HW <= a.Wi) & (src_c0 + 32 <= a.Cin);
+  const bool interior = valid & (od >= 0) & (od + sx * (g.HD - 1) < a.Di) & (oh >= 0) & (oh + sx * (g.HH - 1) < a.Hi) & (ow >= 0) &
+                        (ow + sx * (g.HW - 1) < a.Wi) & (src_c0 + 32 <= a.Cin);
   if (interior) {
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
@@ -856,7 +863,7 @@ __device__ __forceinline__ void dma_issue_x(const DmaPieces<MAXP>& d, const Conv
     const int i = first + stride * k;
     if (i >= npieces) break;  // wave-uniform
     const int pk = d.pk[k];
-    const int gd = od + (pk >> 20), gh = oh + ((pk >> 10) & 1023), gw = ow + (pk & 1023);
+    const int gd = od + sx * (pk >> 20), gh = oh + sx * ((pk >> 10) & 1023), gw = ow + sx * (pk & 1023);
     const bool ok = valid & (pk >= 0) & ((unsigned)gd < (unsigned)a.Di) & ((unsigned)gh < (unsigned)a.Hi) & ((unsigned)gw < (unsigned)a.Wi) & (c + 8 <= a.Cin);
     const unsigned off = ok ? d.off[k] + base : 0xfffffff0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void_t*)(dst + i * 1024), 16, off, 0, 0, 0);
@@ -864,7 +871,7 @@ __device__ __forceinline__ void dma_issue_x(const DmaPieces<MAXP>& d, const Conv
 }
 // dY tile image: [TD][TH][TW] voxels x 64 B, channels y*32 ..
 template <int MAXP>
-__device__ __forceinline__ void dma_init_y(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane, int Ho, int Wo, int cs) {
+__device__ __forceinline__ void dma_init_y(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane, int Ho, int Wo, int cs, int sy = 1) {
   const int nvox = g.TD * g.TH * g.TW;
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
@@ -872,18 +879,19 @@ __device__ __forceinline__ void dma_init_y(DmaPieces<MAXP>& d, const Geom& g, in
     const int v = i * 16 + (lane >> 2);
     const int vd = v / (g.TH * g.TW), rem = v - vd * (g.TH * g.TW), vh = rem / g.TW, vw = rem - vh * g.TW;
     d.pk[k] = (i < npieces && v < nvox) ? ((vd << 20) | (vh << 10) | vw) : -1;
-    d.off[k] = (i < npieces && v < nvox) ? (unsigned)(((vd * Ho + vh) * Wo + vw) * cs + (lane & 3) * 8) * 2u : 0u;
+    d.off[k] = (i < npieces && v < nvox) ? (unsigned)(((sy * vd * Ho + sy * vh) * Wo + sy * vw) * cs + (lane & 3) * 8) * 2u : 0u;
   }
 }
 template <int MAXP>
 __device__ __forceinline__ void dma_issue_y(const DmaPieces<MAXP>& d, const WgradArgs& w, char* dst, int first, int stride, int npieces, int lane,
-                                            int y, int n, int d0, int h0, int w0, bool valid = true) {
+                                            int y, int n, int d0, int h0, int w0, bool valid = true, int sy = 1, int phase = 0) {
   const ConvArgs& a = w.c;
   const __amdgpu_buffer_rsrc_t ry = make_rsrc(w.dy, w.dy_bytes);
   const int co = y * 32 + (lane & 3) * 8;
   const Geom& g = a.g;
-  const unsigned base = (unsigned)((((n * a.Do + d0) * a.Ho + h0) * a.Wo + w0) * w.dy_cs + y * 32) * 2u;  // scalar (mod 2^32)
-  const bool interior = valid & (d0 + g.TD <= a.Do) & (h0 + g.TH <= a.Ho) & (w0 + g.TW <= a.Wo) & (y * 32 + 32 <= a.Cout);
+  const int yd = sy * d0 + ((phase >> 2) & 1), yh = sy * h0 + ((phase >> 1) & 1), yw = sy * w0 + (phase & 1);  // dY voxel of the tile origin
+  const unsigned base = (unsigned)((((n * a.Do + yd) * a.Ho + yh) * a.Wo + yw) * w.dy_cs + y * 32) * 2u;  // scalar (mod 2^32)
+  const bool interior = valid & (yd + sy * (g.TD - 1) < a.Do) & (yh + sy * (g.TH - 1) < a.Ho) & (yw + sy * (g.TW - 1) < a.Wo) & (y * 32 + 32 <= a.Cout);
   if (interior) {
 #pragma unroll
     for (int k = 0; k < MAXP; ++k) {
@@ -898,7 +906,7 @@ __device__ __forceinline__ void dma_issue_y(const DmaPieces<MAXP>& d, const Wgra
     const int i = first + stride * k;
     if (i >= npieces) break;
     const int pk = d.pk[k];
-    const int od = d0 + (pk >> 20), oh = h0 + ((pk >> 10) & 1023), ow = w0 + (pk & 1023);
+    const int od = yd + sy * (pk >> 20), oh = yh + sy * ((pk >> 10) & 1023), ow = yw + sy * (pk & 1023);
     const bool ok = valid & (pk >= 0) & (od < a.Do) & (oh < a.Ho) & (ow < a.Wo) & (co + 8 <= a.Cout);
     const unsigned off = ok ? d.off[k] + base : 0xfffffff0u;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_void_t*)(dst + i * 1024), 16, off, 0, 0, 0);
@@ -959,6 +967,7 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
   const int y = pair / a.nchunks;
   const int* hdr = a.hdr + (int64_t)pair * 4;
   const int tap_begin = hdr[0], ntaps = hdr[1], src_c0 = hdr[2];
+  const int cls = (w.sx > 1 || w.sy > 1) ? hdr[3] & 7 : 0;  // class of the x image / phase of the dY image (factor-2 layers read in place)
   const bool ksplit = !GEO3D && ntaps == 1;
 
   if (wave >= 8) {  // ---------------------------------------------------------------- loader waves
@@ -967,8 +976,8 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     const int first = wave - 8;
     DmaPieces<MAXPX> dx;
     DmaPieces<MAXPY> dyp;
-    dma_init_x<MAXPX>(dx, g, first, 4, px, lane, a.Hi, a.Wi, a.x_cs);
-    dma_init_y<MAXPY>(dyp, g, first, 4, py, lane, a.Ho, a.Wo, w.dy_cs);
+    dma_init_x<MAXPX>(dx, g, first, 4, px, lane, a.Hi, a.Wi, a.x_cs, w.sx);
+    dma_init_y<MAXPY>(dyp, g, first, 4, py, lane, a.Ho, a.Wo, w.dy_cs, w.sy);
     // ring of NB image pairs (w.nbuf: 2, or 4 for the 1x1 k-split pairs whose tiles are all loads and hardly any MFMA): tile i
     // lives in slot i % NB and is requested NB-1 tiles ahead.  Requests beyond the last tile are still issued (all lanes out of
     // range: zeros into a free slot) so that the counted vmcnt below stays exact.
@@ -982,8 +991,8 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
       if (!first_request) walk_step(walk, g);
       first_request = false;
       walk_origin(walk, g, n, d0, h0, w0);  // (past the end: every lane is masked, the origin does not matter)
-      dma_issue_x<MAXPX>(dx, a, lds + slot * XB, first, 4, px, lane, n, d0, h0, w0, src_c0, valid);
-      dma_issue_y<MAXPY>(dyp, w, lds + NB * XB + slot * YB, first, 4, py, lane, y, n, d0, h0, w0, valid);
+      dma_issue_x<MAXPX>(dx, a, lds + slot * XB, first, 4, px, lane, n, d0, h0, w0, src_c0, valid, w.sx, w.sx > 1 ? cls : 0);
+      dma_issue_y<MAXPY>(dyp, w, lds + NB * XB + slot * YB, first, 4, py, lane, y, n, d0, h0, w0, valid, w.sy, w.sy > 1 ? cls : 0);
     };
     auto wait_next = [&]() {  // everything but the NB-2 youngest tiles of this wave has landed (4 + 4 pieces per tile and wave when NB = 4)
       if (NB == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
@@ -1050,7 +1059,8 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
   TileWalk walk;
   walk_init(walk, g, t0, tstep);
   walk_origin(walk, g, n, d0, h0, w0);
-  const bool do_colsum = w.colsum != nullptr && (pair % a.nchunks) == 0;
+  const bool do_colsum = w.colsum != nullptr && (pair % a.nchunks) < w.cs_chunks;
+  const int cs_slab = split * w.cs_chunks + (pair % a.nchunks);  // (column-sum slab of this workgroup: one per split and owning chunk slot)
   const bool cs_wave = do_colsum && (ksplit || wave == 7);
   f32x16& cs = acc[3];
   auto cs_flush = [&](int img) {
@@ -1060,7 +1070,7 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
       for (int e = 0; e < 16; ++e) {
         const int co = y * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
         if (co < a.Cout) {
-          if (w.cs_part && !ksplit) w.cs_part[((int64_t)split * a.N + img) * a.Cout + co] = cs[e];
+          if (w.cs_part && !ksplit) w.cs_part[((int64_t)cs_slab * a.N + img) * a.Cout + co] = cs[e];
           else atomicAdd(w.colsum + (int64_t)img * w.colsum_stride + co, cs[e]);
         }
       }
@@ -1072,7 +1082,7 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
   if (cs_wave && w.cs_part && !ksplit) {  // rows of images this workgroup never reaches must read as zero
     for (int i = lane; i < a.N * 32; i += 64) {
       const int img = i >> 5, co = y * 32 + (i & 31);
-      if (co < a.Cout) w.cs_part[((int64_t)split * a.N + img) * a.Cout + co] = 0.f;
+      if (co < a.Cout) w.cs_part[((int64_t)cs_slab * a.N + img) * a.Cout + co] = 0.f;
     }
   }
   __builtin_amdgcn_s_barrier();  // prologue: tile 0 is in slot 0
@@ -1171,6 +1181,174 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
 // of just one of them (the other stayed an undefined symbol of the shared object; no diagnostic).
 template __global__ void k_conv_wgrad2<true>(WgradArgs);
 template __global__ void k_conv_wgrad2<false>(WgradArgs);
+
+// ------------------------------------------------------------------------------------------------ weight gradient of Upsample + conv
+// dW'[p][t][co][ci] = sum_i dY[2i + p][co] x[i + p + t - 1][ci]  (p: output phase, t: tap of the 2x2x2 box; convph.hip), folded into the 27
+// torch taps by k_wgrad_reduce_up.  Workgroup = (cout block, cin chunk) x a share of the COARSE tiles; the 8 compute waves are the 8
+// box taps, each with 8 accumulators (one per phase); 4 loader waves.  Per tile the coarse x halo image is fetched ONCE (2 slots) and
+// the 8 phase sub-lattices of the fine dY stream through a ring of 4 slots (LDS-DMA with doubled voxel steps: no up-sampled x, no
+// re-laid-out dY in HBM); hand-off by the LDS counters of k_conv_wgrad2.  (A first version ran the phases as separate pairs of
+// k_conv_wgrad2: 54 KB of images per 16 MFMAs of a wave, 4.4 us per tile of pure fetch latency: 565 us for the 64 -> 64 layer at 128^3.)
+// Registers: a wave's accumulators for all 8 phases (128) + the column-sum accumulator do not fit the 168 VGPRs of a 12-wave workgroup
+// (228 bytes of scratch per lane), so a workgroup takes the 4 phases of one d-parity (`half`): 64 accumulator registers, and the two
+// halves of a (cout block, cin chunk) run as separate workgroups that each fetch the x halo.
+constexpr int WGU_XSLOT = 40960, WGU_YSLOT = 16384, WGU_NBY = 4;
+__global__ void __launch_bounds__(768, 3) k_wgrad_up(WgradArgs w) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const ConvArgs& a = w.c;
+  const Geom& g = a.g;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned lds_base = (unsigned)(size_t)(lds_char*)lds;
+  unsigned* const fl = (unsigned*)(lds + 2 * WGU_XSLOT + WGU_NBY * WGU_YSLOT);  // x_ready[2], x_freed[2], y_ready[4], y_freed[4]
+  unsigned* const x_ready = fl, * const x_freed = fl + 2, * const y_ready = fl + 4, * const y_freed = fl + 8;
+  if (threadIdx.x < 12) fl[threadIdx.x] = 0u;
+  int pair, split;  // pair = ((y * nch + ch) * 2 + half)
+  if (w.nsplit >= 8) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    pair = slot % w.npairs;
+    split = (slot / w.npairs) * 8 + xcd;
+  } else {
+    pair = blockIdx.x / w.nsplit;
+    split = blockIdx.x % w.nsplit;
+  }
+  if (split >= w.nsplit || pair >= w.npairs || split >= w.ntiles) return;  // whole workgroup, before any barrier
+  int t0 = split, tstep = w.nsplit, tend = w.ntiles;
+  if (w.contig && w.nsplit >= 8) {
+    const int tpx = w.ntiles >> 3;
+    t0 = (blockIdx.x & 7) * tpx + (blockIdx.x >> 3) / w.npairs;
+    tstep = w.nsplit >> 3;
+    tend = ((blockIdx.x & 7) + 1) * tpx;
+  }
+  const int nch = a.nchunks;  // 32-channel chunks of x
+  const int half = pair & 1, yc = pair >> 1;
+  const int y = yc / nch, src_c0 = (yc % nch) * 32;
+  const int T = (tend - t0 + tstep - 1) / tstep;  // tiles of this workgroup (>= 1)
+  const int S = 4 * T;                            // steps = (tile, phase of this half)
+
+  if (wave >= 8) {  // ---------------------------------------------------------------- loader waves
+    const int first = wave - 8;
+    DmaPieces<10> dx;
+    DmaPieces<4> dyp;
+    dma_init_x<10>(dx, g, first, 4, 40, lane, a.Hi, a.Wi, a.x_cs);
+    dma_init_y<4>(dyp, g, first, 4, 16, lane, a.Ho, a.Wo, w.dy_cs, 2);
+    TileWalk wx, wy;  // tiles of the x requests / of the dY requests (the dY requests run up to 3 steps ahead: maybe in the next tile)
+    walk_init(wx, g, t0, tstep);
+    walk_init(wy, g, t0, tstep);
+    int itx = 0, ity = 0;  // tile iteration the walks stand at
+    auto request_x = [&](int it) {  // (called with it = 0, 1, 2, ...)
+      if (it > itx) { walk_step(wx, g); itx = it; }
+      int n, d0, h0, w0;
+      walk_origin(wx, g, n, d0, h0, w0);
+      dma_issue_x<10>(dx, a, lds + (it & 1) * WGU_XSLOT, first, 4, 40, lane, n, d0, h0, w0, src_c0, it < T);
+    };
+    auto request_y = [&](int s) {  // (called with s = 0, 1, 2, ...)
+      const int it = s >> 2;
+      if (it > ity) { walk_step(wy, g); ity = it; }
+      int n, d0, h0, w0;
+      walk_origin(wy, g, n, d0, h0, w0);
+      dma_issue_y<4>(dyp, w, lds + 2 * WGU_XSLOT + (s & 3) * WGU_YSLOT, first, 4, 16, lane, y, n, d0, h0, w0, s < S, 2, half * 4 + (s & 3));
+    };
+    request_x(0);
+    request_y(0); request_y(1); request_y(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // x(0) and dY(0) have landed
+    __builtin_amdgcn_s_barrier();                     // prologue (also orders the counters' zero-fill)
+    flag_bump(x_ready + 0, lane);
+    flag_bump(y_ready + 0, lane);
+    for (int s = 0;; ++s) {
+      // (1) requests of step s + 3: the dY slot's previous tenant was step s - 1; a new tile's x slot held tile it' - 2
+      const int s3 = s + 3;
+      bool xnew = false;
+      if ((s3 & 3) == 0) {
+        const int itn = s3 >> 2;
+        if (itn >= 2) flag_wait(x_freed + (itn & 1), 8u * (unsigned)(itn >> 1));
+        request_x(itn);
+        xnew = true;
+      }
+      if (s3 >= WGU_NBY) flag_wait(y_freed + (s3 & 3), 8u * (unsigned)(s3 >> 2));
+      request_y(s3);
+      // (2) dY(s + 1) has landed: younger are dY(s + 2), dY(s + 3) and the x image if it went out with one of them
+      if (xnew || ((s + 2) & 3) == 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (s + 1 >= S) break;
+      if (((s + 1) & 3) == 0) flag_bump(x_ready + (((s + 1) >> 2) & 1), lane);  // (older than dY(s + 1): landed as well)
+      flag_bump(y_ready + ((s + 1) & 3), lane);
+    }
+    __builtin_amdgcn_s_barrier();  // every compute wave has finished its last step
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------ compute waves: wave = box tap t
+  const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int kh = gq >> 1;
+  const int chan_b = ((gq & 1) * 16 + pp * 4) * 2;
+  f32x16 acc[4], cs;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[p][e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) cs[e] = 0.f;
+  // tap t = wave of the box, shifted by this half's d-phase
+  const unsigned tapoff = (unsigned)((((wave >> 2) & 1) + half) * WG3_XSLICE + ((wave >> 1) & 1) * WG3_XROW + (wave & 1) * 64);
+  // the dY column sums (bias gradient) of phase half * 4 + j are accumulated by wave j, for the pairs of the first cin chunk
+  const bool do_colsum = w.colsum != nullptr && (yc % nch) == 0 && wave < 4;
+  const int cs_slab = split * 8 + half * 4 + (wave & 3);
+  TileWalk walk;
+  walk_init(walk, g, t0, tstep);
+  int n, d0, h0, w0;
+  walk_origin(walk, g, n, d0, h0, w0);
+  int cs_n = n;
+  auto cs_flush = [&](int img) {
+    if ((lane & 31) == 0) {
+      const int hh = lane >> 5;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = y * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (co < a.Cout) w.cs_part[((int64_t)cs_slab * a.N + img) * a.Cout + co] = cs[e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[e] = 0.f;
+  };
+  if (do_colsum) {  // rows of images this workgroup never reaches must read as zero
+    for (int i = lane; i < a.N * 32; i += 64) {
+      const int img = i >> 5, co = y * 32 + (i & 31);
+      if (co < a.Cout) w.cs_part[((int64_t)cs_slab * a.N + img) * a.Cout + co] = 0.f;
+    }
+  }
+  __builtin_amdgcn_s_barrier();  // prologue
+  for (int it = 0; it < T; ++it) {
+    if (do_colsum && n != cs_n) { cs_flush(cs_n); cs_n = n; }
+    flag_wait(x_ready + (it & 1), 4u * (unsigned)((it >> 1) + 1));
+    const unsigned xb = lds_base + (it & 1) * WGU_XSLOT + tapoff;
+    const unsigned yb0 = lds_base + 2 * WGU_XSLOT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // phase half * 4 + j: (h, w) phase = j
+      flag_wait(y_ready + j, 4u * (unsigned)(it + 1));
+      const int one[1] = {((j >> 1) & 1) * WG3_XROW + (j & 1) * 64};
+      f32x16(&a1)[1] = reinterpret_cast<f32x16(&)[1]>(acc[j]);
+      if (do_colsum && wave == j) wg3_tile<1, true>(a1, one, cs, xb, yb0 + j * WGU_YSLOT, kh, q, chan_b);
+      else wg3_tile<1, false>(a1, one, cs, xb, yb0 + j * WGU_YSLOT, kh, q, chan_b);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      flag_bump(y_freed + j, lane);
+    }
+    flag_bump(x_freed + (it & 1), lane);
+    if (it + 1 < T) { walk_step(walk, g); walk_origin(walk, g, n, d0, h0, w0); }
+  }
+  __builtin_amdgcn_s_barrier();  // (pairs with the loaders')
+  if (do_colsum) cs_flush(cs_n);
+  float* out = w.part + (int64_t)split * w.split_stride + ((int64_t)yc * 64 + half * 32 + wave) * 1024;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = (e & 3) + 8 * (e >> 2) + 4 * h;
+      out[(int64_t)p * 8 * 1024 + co * 32 + r] = acc[p][e];
+    }
+}
 
 // ------------------------------------------------------------------------------------------------ weight pack / unpack
 // frag_items[f] = {src_tap, co0, ci0, flags}: fragment f holds A[row = co0 + r][k = ci0 + 8h + j] (kernel channel indices);
@@ -1377,6 +1555,62 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce_rows(const float* __restri
   }
 }
 
+// Upsample + conv: k_wgrad_up produced dW'[phase p][box tap t] (slab item (pair * 8 + p) * 8 + t); torch tap k = (kd, kh, kw) is the sum
+// of the 8 (p, t) whose tap set holds it -- per axis k = 0: (p,t) in {(0,0), (1,0)}, k = 1: {(0,1), (1,0)}, k = 2: {(0,1), (1,1)} (the sets
+// S(p,t) of convph.hip read backwards).  A block owns one output row of a (cout block, cin chunk) pair: 8 thread groups split the
+// slabs, each thread sums its share of the row's 64 items for one input channel (64 independent accumulators), LDS folds the groups,
+// and the 27 taps leave as one contiguous run of 32 * 27 floats.
+__global__ void __launch_bounds__(256) k_wgrad_reduce_up(const float* __restrict__ part, int64_t split_stride, int nsplit, int nch, float* __restrict__ dw,
+                                                         int Co_t, int Ci_t, CsReduce cs, int nmain) {
+  __shared__ float red[8][16][33];
+  __shared__ float items[64][33];
+  __shared__ float outp[32][28];
+  if ((int)blockIdx.x >= nmain) { cs_reduce_block(cs, blockIdx.x - nmain); return; }
+  const int yc = blockIdx.x >> 5, co_l = blockIdx.x & 31;
+  const int y = yc / nch, ch = yc % nch;
+  const int co = y * 32 + co_l, ci0 = ch * 32;
+  if (co >= Co_t) return;  // whole block
+  const int ci_l = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const float* base = part + (int64_t)yc * 64 * 1024 + co_l * 32 + ci_l;
+  for (int i0 = 0; i0 < 64; i0 += 16) {  // 16 items at a time (LDS)
+    float a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = 0.f;
+    for (int sp = grp; sp < nsplit; sp += 8) {
+      const float* q = base + (int64_t)sp * split_stride + (int64_t)i0 * 1024;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) a[i] += q[i * 1024];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[grp][i][ci_l] = a[i];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 16 * 32; e += 256) {
+      const int i = e >> 5, c = e & 31;
+      items[i0 + i][c] = ((red[0][i][c] + red[1][i][c]) + (red[2][i][c] + red[3][i][c])) + ((red[4][i][c] + red[5][i][c]) + (red[6][i][c] + red[7][i][c]));
+    }
+    __syncthreads();
+  }
+  for (int e = threadIdx.x; e < 27 * 32; e += 256) {
+    const int k = e >> 5, c = e & 31;
+    const int ka[3] = {k / 9, (k / 3) % 3, k % 3};
+    float v = 0.f;
+    for (int m = 0; m < 8; ++m) {  // one of the two (p, t) options per axis
+      int p = 0, t = 0;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const int pa = (m >> (2 - ax)) & 1, ta = ka[ax] == 0 ? 0 : (ka[ax] == 1 ? 1 - pa : 1);  // k in S(pa, ta)
+        p = p * 2 + pa; t = t * 2 + ta;
+      }
+      v += items[p * 8 + t][c];
+    }
+    outp[c][k] = v;
+  }
+  __syncthreads();
+  const int nci = Ci_t - ci0 < 32 ? Ci_t - ci0 : 32;
+  float* row = dw + ((int64_t)co * Ci_t + ci0) * 27;
+  for (int e = threadIdx.x; e < nci * 27; e += 256) row[e] += outp[e / 27][e % 27];
+}
+
 int env_int(const char* name, int dflt);
 // cs: the conv's column-sum partials to fold in the same launch (cs.part == nullptr: none)
 inline void launch_wgrad_reduce(const float* part, int64_t split_stride, int nsplit, const int* uitems, int nitems, float* dw, int Co_t, int Ci_t,
@@ -1450,7 +1684,11 @@ struct mi_conv_plan {
   int N, Di, Hi, Wi, Cin, Cout, k[3], s[3], p[3];
   bool up = false;         // nearest x2 interpolation in front of the k3 s1 p1 conv (mi_upconv_plan_create): Di.. coarse, Do.. = 2 Di..
   PhaseSide ph_fwd, ph_dg;
-  mi_conv_plan* up_inner = nullptr;  // upconv: plain k3 s1 p1 plan on the fine grid (weight gradient; fallback)
+  mi_conv_plan* up_inner = nullptr;  // upconv: plain k3 s1 p1 plan on the fine grid (fallback when a tensor is not 16-byte pitched)
+  bool up_wg = false;      // upconv: weight gradient by phase pairs on the coarse grid (wg tables / slabs of this plan)
+  int up_nch = 0;          // ... its 32-channel input chunks
+  int* d_hdr2 = nullptr;   // k3 s2 conv: weight-gradient pair headers for reading x in place (channel offset inside the class, class code)
+  bool s2_wg_direct = false;
   bf16* d_xup = nullptr;   // upconv: nearest-upsampled x for up_inner
   int Do, Ho, Wo;
   int f[3], Q;            // space-to-depth factors of x for strided axes
@@ -1700,6 +1938,76 @@ int phase_side_run(const PhaseSide& ps, const void* x, int x_cs, int id, int ih,
   return mi_launch_convph(a, ps.ncb, ps.mode, ntiles, ps.ny, st);
 }
 
+// Weight gradient of Upsample + conv on the coarse grid (k_wgrad_up): pair = (cout block y, cin chunk ch); slabs of 64 items per pair
+int upconv_wgrad_tables(mi_conv_plan* P) {
+  const int halo[3] = {1, 1, 1};
+  P->g_wg = make_geom(2, P->Di, P->Hi, P->Wi, halo, P->N, 64);
+  const Geom& g = P->g_wg;
+  if (g.TD != 4 || g.TH != 8 || g.TW != 8 || g.row != WG3_XROW || g.slice != WG3_XSLICE) return MI_ERR_UNSUPPORTED;
+  const int ny = (P->Cout + 31) / 32, nch = (P->Cin + 31) / 32;
+  P->up_nch = nch;
+  P->wg.ny = ny; P->wg.nchunks = nch;
+  const int npairs = ny * nch * 2;  // (cout block, cin chunk, d-parity half of the phases)
+  P->wg_split_stride = (int64_t)ny * nch * 64 * 1024;
+  const int ntiles = P->N * g.tilesD * g.tilesH * g.tilesW;
+  int nsplit = 1;
+  {  // (the cost model of mi_conv_plan_create: rounds per XCD x (tiles per workgroup + fixed costs); a tile here is 8 phase steps)
+    int64_t best = -1;
+    for (int ns = 1; ns <= 256 && ns <= ntiles; ++ns) {
+      const int per_xcd = ns >= 8 ? npairs * ((ns + 7) / 8) : (npairs * ns + 7) / 8;
+      const int64_t rounds = (per_xcd + 31) / 32, cost = rounds * ((ntiles + ns - 1) / ns + 2);
+      if (best < 0 || cost < best) { best = cost; nsplit = ns; }
+    }
+  }
+  static const int ns_env = env_int("MI_WGU_NSPLIT", 0);
+  if (ns_env > 0 && ns_env <= ntiles) nsplit = ns_env;
+  while (nsplit > 1 && (int64_t)nsplit * P->wg_split_stride * 4 > (256ll << 20)) nsplit /= 2;
+  P->wg_nsplit = nsplit;
+  if (hipMalloc((void**)&P->d_part, (size_t)nsplit * P->wg_split_stride * 4) != hipSuccess) return (int)hipErrorOutOfMemory;
+  if (hipMalloc((void**)&P->d_cspart, (size_t)nsplit * 8 * P->N * P->Cout * 4) != hipSuccess) return (int)hipErrorOutOfMemory;
+  return 0;
+}
+
+int upconv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const void* dy, int dy_cs, float* dw, float* dy_colsum, int dy_colsum_stride, hipStream_t st) {
+  if (dy_colsum && dy_colsum_stride != 0 && dy_colsum_stride < P->Cout) return MI_ERR_BAD_ARG;
+  WgradArgs w;
+  memset(&w, 0, sizeof(w));
+  ConvArgs& a = w.c;
+  a.x = (const bf16*)x; a.x_cs = x_cs; a.N = P->N; a.Di = P->Di; a.Hi = P->Hi; a.Wi = P->Wi; a.Cin = P->Cin;
+  a.Cout = P->Cout; a.Do = P->Do; a.Ho = P->Ho; a.Wo = P->Wo;  // dY: the fine grid
+  a.nchunks = P->up_nch;
+  a.g = P->g_wg;
+  const int64_t xb = (int64_t)P->N * P->Di * P->Hi * P->Wi * x_cs * 2, dyb = (int64_t)P->N * P->Do * P->Ho * P->Wo * dy_cs * 2;
+  if (xb >= (1ll << 32) || dyb >= (1ll << 32)) return MI_ERR_UNSUPPORTED;
+  a.x_bytes = (unsigned)xb;
+  w.dy = (const bf16*)dy; w.dy_cs = dy_cs; w.dy_bytes = (unsigned)dyb;
+  w.sx = 1; w.sy = 2; w.cs_chunks = 1;
+  w.part = P->d_part; w.split_stride = P->wg_split_stride;
+  w.ntiles = P->N * a.g.tilesD * a.g.tilesH * a.g.tilesW;
+  w.nsplit = P->wg_nsplit;
+  static const int contig_env = env_int("MI_WGRAD_CONTIG", 1);
+  w.contig = contig_env && (w.ntiles % 8 == 0) && (w.nsplit % 8 == 0) && w.nsplit <= w.ntiles;
+  w.colsum = dy_colsum; w.colsum_stride = dy_colsum_stride;
+  w.cs_part = dy_colsum ? P->d_cspart : nullptr;
+  w.npairs = P->wg.ny * P->up_nch * 2;
+  const size_t lds = 2 * WGU_XSLOT + WGU_NBY * WGU_YSLOT + 64;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_wgrad_up, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  dim3 grid(w.nsplit >= 8 ? w.npairs * ((w.nsplit + 7) / 8) * 8 : w.npairs * w.nsplit);
+  hipLaunchKernelGGL(k_wgrad_up, grid, dim3(768), lds, st, w);
+  CsReduce cs{w.cs_part, P->wg_nsplit * 8, P->N, P->Cout, dy_colsum, dy_colsum_stride, 0};
+  cs.nbx = (cs.Cout + 31) / 32;
+  const int extra = cs.part ? cs.nbx * cs.N : 0, nmain = P->wg.ny * P->up_nch * 32;
+  hipLaunchKernelGGL(k_wgrad_reduce_up, dim3(nmain + extra), dim3(256), 0, st, P->d_part, P->wg_split_stride, P->wg_nsplit, P->up_nch, dw, P->Cout,
+                     P->Cin, cs, nmain);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1818,6 +2126,17 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
       int e1 = phase_side_create(P->ph_fwd, S2_FWD, 2, 0, Cout, Cin, P->Do, P->Ho, P->Wo, N);
       int e2 = e1 ? e1 : phase_side_create(P->ph_dg, S2_DG, 1, 1, Cin, Cout, P->Do, P->Ho, P->Wo, N);
       if (e1 || e2) { phase_side_free(P->ph_fwd); phase_side_free(P->ph_dg); if ((e1 ? e1 : e2) != MI_ERR_UNSUPPORTED) { mi_conv_plan_destroy(P); return e1 ? e1 : e2; } }
+      if (P->ph_fwd.mode && (Cin % 32) == 0) {  // weight gradient: the class images are gathered from x in place (k_conv_wgrad2, sx = 2)
+        std::vector<int> h2 = P->wg.hdr;
+        const int cpq = Cin / 32;  // chunks per class
+        for (int pr = 0; pr < P->wg.ny * P->wg.nchunks; ++pr) {
+          const int ch = pr % P->wg.nchunks, q = ch / cpq;
+          h2[(size_t)pr * 4 + 2] = (ch % cpq) * 32;
+          h2[(size_t)pr * 4 + 3] = q;  // (qd, qh, qw) = bits 2, 1, 0: all three factors are 2
+        }
+        if ((e = upload(h2, &P->d_hdr2))) { mi_conv_plan_destroy(P); return e; }
+        P->s2_wg_direct = true;
+      }
     }
   }
   if (P->strided) {
@@ -1831,6 +2150,7 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
 int mi_conv_plan_destroy(mi_conv_plan* P) {
   if (!P) return 0;
   phase_side_free(P->ph_fwd); phase_side_free(P->ph_dg);
+  if (P->d_hdr2) (void)hipFree(P->d_hdr2);
   if (P->up_inner) mi_conv_plan_destroy(P->up_inner);
   if (P->d_xup) (void)hipFree(P->d_xup);
   free_tables(P->fwd); free_tables(P->dg); free_tables(P->wg);
@@ -1867,6 +2187,11 @@ int mi_upconv_plan_create(mi_conv_plan** out, int N, int D, int H, int W, int Ci
     int e1 = phase_side_create(P->ph_fwd, UC_FWD, 1, 0, Cout, Cin, D, H, W, N);
     int e2 = e1 ? e1 : phase_side_create(P->ph_dg, UC_DG, 2, 1, Cin, Cout, D, H, W, N);
     if (e1 || e2) { phase_side_free(P->ph_fwd); phase_side_free(P->ph_dg); if ((e1 ? e1 : e2) != MI_ERR_UNSUPPORTED) { mi_conv_plan_destroy(P); return e1 ? e1 : e2; } }
+    if (P->ph_fwd.mode) {
+      const int ew = upconv_wgrad_tables(P);
+      if (ew && ew != MI_ERR_UNSUPPORTED) { mi_conv_plan_destroy(P); return ew; }
+      P->up_wg = ew == 0;
+    }
   }
   *out = P;
   return 0;
@@ -2120,7 +2445,11 @@ int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_c
 int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const void* dy, int dy_cs, float* dw,
                   float* dy_colsum, int dy_colsum_stride, hipStream_t st) {
   if (!P || !x || !dy || !dw || x_cs < P->Cin || dy_cs < P->Cout) return MI_ERR_BAD_ARG;
-  if (P->up) {  // weight gradient of Upsample + conv: on the fine grid against the nearest-upsampled x
+  if (P->up && P->up_wg && !scale_shift && (x_cs & 7) == 0 && (dy_cs & 7) == 0) {
+    const int e = upconv_wgrad(P, x, x_cs, dy, dy_cs, dw, dy_colsum, dy_colsum_stride, st);
+    if (e != MI_ERR_UNSUPPORTED) return e;
+  }
+  if (P->up) {  // fallback: on the fine grid against the nearest-upsampled x
     if (x_cs != P->Cin || scale_shift) return MI_ERR_UNSUPPORTED;
     int e = mi_upsample_nearest_fwd(x, P->d_xup, P->N, P->Di, P->Hi, P->Wi, P->Cin, 2, 2, 2, st);
     if (e) return e;
@@ -2140,20 +2469,31 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   }
   WgradArgs w;
   memset(&w, 0, sizeof(w));
+  w.sx = w.sy = 1; w.cs_chunks = 1;
   ConvArgs& a = w.c;
   const bf16* src = (const bf16*)x;
   int src_cs = x_cs;
-  if (P->strided) {
+  static const int use_w2 = env_int("MI_WGRAD2", 1);
+  // k3 s2 conv on all axes: the LDS-DMA kernel gathers each pair's class image from x in place (sx = 2) -- no space-to-depth copy
+  bool direct = false;
+  if (P->s2_wg_direct && use_w2 && !scale_shift && (x_cs & 7) == 0 && (dy_cs & 7) == 0 && (P->Cout & 7) == 0 && P->g_wg.vox == 64) {
+    const int px = (P->g_wg.lds_bytes + 1023) / 1024, py = (P->g_wg.TD * P->g_wg.TH * P->g_wg.TW * 64 + 1023) / 1024;
+    const int64_t dyb = (int64_t)P->N * P->Do * P->Ho * P->Wo * dy_cs * 2, xb = (int64_t)P->N * P->Di * P->Hi * P->Wi * x_cs * 2;
+    direct = px <= 40 && py <= 16 && dyb < (1ll << 32) && xb < (1ll << 32);
+  }
+  if (P->strided && !direct) {
     int e = mi_space_to_depth(x, x_cs, P->d_xs, P->N, P->Di, P->Hi, P->Wi, P->Cin, P->f[0], P->f[1], P->f[2], st);
     if (e) return e;
     src = P->d_xs;
     src_cs = P->Q * P->Cin;
   }
+  const bool s2d = P->strided && !direct;
   a.x = src; a.x_cs = src_cs; a.N = P->N;
-  a.Di = P->strided ? P->Dp : P->Di; a.Hi = P->strided ? P->Hp : P->Hi; a.Wi = P->strided ? P->Wp : P->Wi;
-  a.Cin = P->strided ? P->Q * P->Cin : P->Cin;
+  a.Di = s2d ? P->Dp : P->Di; a.Hi = s2d ? P->Hp : P->Hi; a.Wi = s2d ? P->Wp : P->Wi;
+  a.Cin = s2d ? P->Q * P->Cin : P->Cin;
   a.Cout = P->Cout; a.Do = P->Do; a.Ho = P->Ho; a.Wo = P->Wo;
-  a.hdr = P->wg.d_hdr; a.taps = P->wg.d_taps; a.nchunks = P->wg.nchunks;
+  a.hdr = direct ? P->d_hdr2 : P->wg.d_hdr; a.taps = P->wg.d_taps; a.nchunks = P->wg.nchunks;
+  if (direct) w.sx = 2;
   a.ss = scale_shift; a.ss_C = P->Cin; a.pro_silu = silu;
   {
     int64_t xb = (int64_t)a.N * a.Di * a.Hi * a.Wi * a.x_cs * 2;
@@ -2199,7 +2539,6 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
     hipLaunchKernelGGL(kern, grid, blk, lds, st, w);                                                               \
   } while (0)
   // LDS-DMA kernel (k_conv_wgrad2): whole 8-channel pieces only, no fused prologue
-  static const int use_w2 = env_int("MI_WGRAD2", 1);
   {
     const int px = (a.g.lds_bytes + 1023) / 1024, py = (nvox * 64 + 1023) / 1024;
     const int64_t dyb = (int64_t)P->N * P->Do * P->Ho * P->Wo * dy_cs * 2;

@@ -30,7 +30,8 @@ template <int NCB, int MODE>
 int launchph(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   using KK = K<NCB, MODE>;
   a.ntiles = ntiles;
-  a.dbg = 0;
+  static const char* dbg_env = getenv("MI_CPH_DBG");  // ablation knob: 1 = no store epilogue (results are garbage)
+  a.dbg = dbg_env ? atoi(dbg_env) & 1 : 0;
   a.stats = nullptr; a.stats_chunks = 0;
   const int gx = mi_conv27_grid_x(ntiles, ny);
   auto kern = k_convph<NCB, MODE>;
@@ -46,36 +47,56 @@ int launchph(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   return 0;
 }
 
-// One fragment per 64 threads: fragment f = ((y * 8 + pc) * nchunks + ch) * (8 * 2 * NCB) + (t * 2 + ks) * NCB + cb holds
-// A[row -> kernel-out channel (y * NCB + cb) * 32 + perm(rho)][k -> kernel-in channel ch * 32 + ks * 16 + 8h + j] = the sum of the
-// torch weights W[o][i][tap] over the taps of masks[pc * 8 + t] (bit k = tap k of the 27); tr: kernel-out = torch-in (data gradients).
+// Weight pack.  Fragment f = ((y * 8 + pc) * nchunks + ch) * (8 * 2 * NCB) + (t * 2 + ks) * NCB + cb holds
+// A[row -> kernel-out channel (y * NCB + cb) * 32 + perm(rho)][k -> kernel-in channel ch * 32 + ks * 16 + 8h + j] = the sum of the torch
+// weights W[o][i][tap] over the taps of masks[pc * 8 + t] (bit k = tap k of the 27); tr: kernel-out = torch-in (data gradients).
+// A block owns one (32 kernel-out, 16 kernel-in) block: its 32 x 16 x 27 source weights are read once, coalesced (rows of 432 resp.
+// 864 contiguous floats), into LDS and all 64 (phase, tap) fragments are summed from there -- the per-fragment gather from global
+// memory (8 floats per lane at a 108-byte stride, up to 8 taps each) took 150 us for a 256 -> 256 layer, more than the kernel it feeds.
 __global__ void __launch_bounds__(256) k_pack_phase(const float* __restrict__ w, u32x4* __restrict__ out, const unsigned* __restrict__ masks,
-                                                    int nfrags, int NCB, int nchunks, int Ko, int Ki, int Co_t, int Ci_t, int tr) {
-  const int gid = blockIdx.x * 256 + threadIdx.x, f = gid >> 6, lane = gid & 63;
-  if (f >= nfrags) return;
-  int r = f;
-  const int cb = r % NCB; r /= NCB;
-  const int ks = r & 1; r >>= 1;
-  const int t = r & 7; r >>= 3;
-  const int ch = r % nchunks; r /= nchunks;
-  const int pc = r & 7, y = r >> 3;
-  const unsigned m = masks[pc * 8 + t];
-  const int rho = lane & 31;
-  const int crow = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);  // conv27 row permutation: a lane's 16 accumulators = 16 consecutive channels
-  const int ko = (y * NCB + cb) * 32 + crow, ki0 = ch * 32 + ks * 16 + (lane >> 5) * 8;
-  F8 v;
+                                                    int NCB, int nchunks, int Ko, int Ki, int Co_t, int Ci_t, int tr) {
+  extern __shared__ float sm[];
+  const int kb = blockIdx.x / (nchunks * 2), kk = blockIdx.x % (nchunks * 2);
+  const int y = kb / NCB, cb = kb % NCB, ch = kk >> 1, ks = kk & 1;
+  const int ko0 = kb * 32, ki0 = kk * 16;
+  const int rows = tr ? 16 : 32, ni = tr ? 32 : 16;         // torch rows (out channels) / in channels of the block
+  const int o0 = tr ? ki0 : ko0, i0 = tr ? ko0 : ki0;
+  const int run = ni * 27, pitch = run + 1;
+  const int nvalid = (Ci_t - i0 < ni ? (Ci_t - i0 > 0 ? Ci_t - i0 : 0) : ni) * 27;
+  for (int e0 = threadIdx.x; e0 < rows * run; e0 += 8 * 256) {
+    float v[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int ki = ki0 + j;
-    const int o = tr ? ki : ko, i = tr ? ko : ki;  // torch (out, in)
-    float s = 0.f;
-    if (ko < Ko && ki < Ki && o < Co_t && i < Ci_t) {
-      const float* p = w + ((int64_t)o * Ci_t + i) * 27;
-      for (unsigned mm = m; mm; mm &= mm - 1) s += p[__builtin_ctz(mm)];
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256, o = e / run, c = e - o * run;
+      v[u] = (e < rows * run && o0 + o < Co_t && c < nvalid) ? w[((int64_t)(o0 + o) * Ci_t + i0) * 27 + c] : 0.f;
     }
-    v.v[j] = s;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int e = e0 + u * 256, o = e / run, c = e - o * run;
+      if (e < rows * run) sm[o * pitch + c] = v[u];
+    }
   }
-  out[gid] = pack8(v);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rho = lane & 31, h = lane >> 5;
+  const int crow = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);  // conv27 row permutation: a lane's 16 accumulators = 16 consecutive channels
+  const bool row_ok = ko0 + crow < Ko;
+  for (int c = blockIdx.y * 8 + wave; c < blockIdx.y * 8 + 8; c += 4) {  // blockIdx.y = phase: its 8 taps over the 4 waves
+    const int pc = c >> 3, t = c & 7;
+    const unsigned m = masks[c];
+    F8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int kil = 8 * h + j;
+      const int o = tr ? kil : crow, i = tr ? crow : kil;
+      float sacc = 0.f;
+      if (row_ok && ki0 + kil < Ki)
+        for (unsigned mm = m; mm; mm &= mm - 1) sacc += sm[o * pitch + i * 27 + __builtin_ctz(mm)];
+      v.v[j] = sacc;
+    }
+    const int f = ((y * 8 + pc) * nchunks + ch) * (16 * NCB) + (t * 2 + ks) * NCB + cb;
+    out[(int64_t)f * 64 + lane] = pack8(v);
+  }
 }
 
 }  // namespace
@@ -89,9 +110,16 @@ int mi_launch_convph(const ConvArgs& a, int NCB, int mode, int ntiles, int ny, h
 
 int mi_launch_pack_phase(const float* w, void* out, const unsigned* d_masks, int nfrags, int NCB, int nchunks, int Ko, int Ki, int Co_t, int Ci_t,
                          int tr, hipStream_t st) {
-  if (!w || !out || !d_masks || nfrags <= 0) return MI_ERR_BAD_ARG;
-  hipLaunchKernelGGL(k_pack_phase, dim3((nfrags * 64 + 255) / 256), dim3(256), 0, st, w, (u32x4*)out, d_masks, nfrags, NCB, nchunks, Ko, Ki, Co_t,
-                     Ci_t, tr);
+  if (!w || !out || !d_masks || nfrags <= 0 || nfrags % (8 * nchunks * 16 * NCB)) return MI_ERR_BAD_ARG;
+  const int ny = nfrags / (8 * nchunks * 16 * NCB);
+  const size_t lds = sizeof(float) * (size_t)(tr ? 16 * (32 * 27 + 1) : 32 * (16 * 27 + 1));
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_pack_phase, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_pack_phase, dim3(ny * NCB * nchunks * 2, 8), dim3(256), lds, st, w, (u32x4*)out, d_masks, NCB, nchunks, Ko, Ki, Co_t, Ci_t, tr);
   MI_CHECK_LAUNCH();
   return 0;
 }
