@@ -1678,6 +1678,8 @@ struct PhaseSide {
   Geom g;                  // tile grid = the coarse side
   u32x4* d_w = nullptr;    // packed fragments [cout group][phase][chunk][tap][k-step][cout block]
   unsigned* d_masks = nullptr;  // [phase * 8 + tap] -> bit k set: torch tap k is summed into this fragment
+  PhasePackJob* d_job = nullptr;  // one-job table for a pack of this side alone (mi_conv_pack_weights)
+  const float* job_w = nullptr;   // ... the weight pointer it was written for
 };
 
 struct mi_conv_plan {
@@ -1912,11 +1914,22 @@ int phase_side_create(PhaseSide& ps, PhaseKind kind, int mode, int tr, int Ko, i
 void phase_side_free(PhaseSide& ps) {
   if (ps.d_w) (void)hipFree(ps.d_w);
   if (ps.d_masks) (void)hipFree(ps.d_masks);
-  ps.d_w = nullptr; ps.d_masks = nullptr; ps.mode = 0;
+  if (ps.d_job) (void)hipFree(ps.d_job);
+  ps.d_w = nullptr; ps.d_masks = nullptr; ps.d_job = nullptr; ps.mode = 0;
 }
-int phase_side_pack(const PhaseSide& ps, const float* w, int Co_t, int Ci_t, hipStream_t st) {
+PhasePackJob phase_job(const PhaseSide& ps, const float* w, int Co_t, int Ci_t, int block0) {
+  return PhasePackJob{w, ps.d_w, ps.d_masks, ps.ncb, ps.nchunks, ps.Ko, ps.Ki, Co_t, Ci_t, ps.tr, block0};
+}
+// pack of one side alone (plan.pack: first use of a plan, tests); the per-step path is the batch (mi_conv_pack_batch_run)
+int phase_side_pack(PhaseSide& ps, const float* w, int Co_t, int Ci_t, hipStream_t st) {
   if (!ps.mode) return 0;
-  return mi_launch_pack_phase(w, ps.d_w, ps.d_masks, ps.nfrags, ps.ncb, ps.nchunks, ps.Ko, ps.Ki, Co_t, Ci_t, ps.tr, st);
+  if (!ps.d_job || ps.job_w != w) {  // (synchronous upload: not during a capture -- the trainers pack through the batch there)
+    if (!ps.d_job && hipMalloc((void**)&ps.d_job, sizeof(PhasePackJob)) != hipSuccess) return (int)hipErrorOutOfMemory;
+    const PhasePackJob j = phase_job(ps, w, Co_t, Ci_t, 0);
+    if (hipMemcpy(ps.d_job, &j, sizeof(j), hipMemcpyHostToDevice) != hipSuccess) return (int)hipErrorUnknown;
+    ps.job_w = w;
+  }
+  return mi_launch_pack_phase(ps.d_job, 1, mi_pack_phase_blocks(ps.nfrags, ps.ncb, ps.nchunks), st);
 }
 // x: kernel input [N][id][ih][iw] with pitch x_cs, y: kernel output [N][od][oh][ow] with pitch y_cs (one of the two grids is twice the other)
 int phase_side_run(const PhaseSide& ps, const void* x, int x_cs, int id, int ih, int iw, void* y, int y_cs, int od, int oh, int ow, int N,
@@ -2220,13 +2233,13 @@ int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
   return 0;
 }
 
-struct PhaseJob { const PhaseSide* side; const float* w; int Co_t, Ci_t; };
 struct mi_pack_batch {
   PackGroup* d_groups = nullptr;
   int2* d_gtaps = nullptr;
   int ngroups = 0;
   size_t lds = 0;
-  std::vector<PhaseJob> phase;  // phase-kernel sides of the batch's plans: one small launch each (a handful per network)
+  PhasePackJob* d_phase = nullptr;  // phase-kernel sides of the batch's plans: one more launch for all of them
+  int nphase = 0, phase_blocks = 0;
 };
 namespace {
 // groups of one fragment table: fragments keyed by (co0, ci0) in order of first appearance
@@ -2266,12 +2279,16 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
   std::vector<PackGroup> groups;
   std::vector<int2> gtaps;
   size_t lds = 0;
-  std::vector<PhaseJob> phase;
+  std::vector<PhasePackJob> phase;
+  int phase_blocks = 0;
   for (int i = 0; i < n; ++i) {
     mi_conv_plan* P = plans[i];
     if (!P || !weights[i]) return MI_ERR_BAD_ARG;
-    if (P->ph_fwd.mode) phase.push_back(PhaseJob{&P->ph_fwd, weights[i], P->Cout, P->Cin});
-    if (P->ph_dg.mode) phase.push_back(PhaseJob{&P->ph_dg, weights[i], P->Cout, P->Cin});
+    for (PhaseSide* ps : {&P->ph_fwd, &P->ph_dg})
+      if (ps->mode) {
+        phase.push_back(phase_job(*ps, weights[i], P->Cout, P->Cin, phase_blocks));
+        phase_blocks += mi_pack_phase_blocks(ps->nfrags, ps->ncb, ps->nchunks);
+      }
     if (P->up) P = P->up_inner;  // (its tables pack like any k3 s1 conv's)
     P->c1_packed = true;
     const size_t g0 = groups.size();
@@ -2285,7 +2302,14 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
   if (lds > 64 * 1024) return MI_ERR_UNSUPPORTED;
   mi_pack_batch* B = new mi_pack_batch();
   B->ngroups = (int)groups.size(); B->lds = lds;
-  B->phase = phase;
+  B->nphase = (int)phase.size(); B->phase_blocks = phase_blocks;
+  if (B->nphase) {
+    if (hipMalloc((void**)&B->d_phase, sizeof(PhasePackJob) * phase.size()) != hipSuccess ||
+        hipMemcpy(B->d_phase, phase.data(), sizeof(PhasePackJob) * phase.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      mi_conv_pack_batch_destroy(B);
+      return (int)hipErrorOutOfMemory;
+    }
+  }
   if (hipMalloc((void**)&B->d_groups, sizeof(PackGroup) * (groups.size() ? groups.size() : 1)) != hipSuccess ||
       hipMalloc((void**)&B->d_gtaps, sizeof(int2) * (gtaps.size() ? gtaps.size() : 1)) != hipSuccess) {
     mi_conv_pack_batch_destroy(B);
@@ -2301,16 +2325,14 @@ int mi_conv_pack_batch_run(mi_pack_batch* B, hipStream_t st) {
   if (!B) return MI_ERR_BAD_ARG;
   if (B->ngroups) hipLaunchKernelGGL(k_pack_groups, dim3(B->ngroups), dim3(256), B->lds, st, B->d_groups, B->d_gtaps);
   MI_CHECK_LAUNCH();
-  for (const PhaseJob& j : B->phase) {
-    const int e = phase_side_pack(*j.side, j.w, j.Co_t, j.Ci_t, st);
-    if (e) return e;
-  }
+  if (B->nphase) return mi_launch_pack_phase(B->d_phase, B->nphase, B->phase_blocks, st);
   return 0;
 }
 int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
   if (!B) return 0;
   if (B->d_groups) (void)hipFree(B->d_groups);
   if (B->d_gtaps) (void)hipFree(B->d_gtaps);
+  if (B->d_phase) (void)hipFree(B->d_phase);
   delete B;
   return 0;
 }

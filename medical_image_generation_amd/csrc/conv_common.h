@@ -127,8 +127,12 @@ int mi_conv27_grid_x(int ntiles, int ny);  // gridDim.x of that launch (4 statis
 // convph.hip: factor-2 phase convolutions (mode 1 scatter: tile grid = coarse input, fine output; mode 2 gather: fine input, tile grid =
 // coarse output) and their weight pack (fragment = fp32 sum of the master weights over a tap set, d_masks[phase * 8 + tap])
 int mi_launch_convph(const ConvArgs& a, int NCB, int mode, int ntiles, int ny, hipStream_t st);
-int mi_launch_pack_phase(const float* w, void* out, const unsigned* d_masks, int nfrags, int NCB, int nchunks, int Ko, int Ki, int Co_t, int Ci_t,
-                         int tr, hipStream_t st);
+struct PhasePackJob {          // one phase side's weight pack (k_pack_phase); block0 = first blockIdx.x of the job in a batched launch
+  const float* w; void* out; const unsigned* masks;
+  int NCB, nchunks, Ko, Ki, Co_t, Ci_t, tr, block0;
+};
+int mi_pack_phase_blocks(int nfrags, int NCB, int nchunks);  // blocks (along x) of a job: (kernel-out blocks of 32) x (kernel-in blocks of 16)
+int mi_launch_pack_phase(const PhasePackJob* d_jobs, int njobs, int total_blocks, hipStream_t st);
 // conv1x1.hip: 1x1x1 forward / data gradient as a streaming GEMM over voxels
 int mi_launch_conv1x1(const ConvArgs& a, int NCB, int ny, hipStream_t st);
 int mi_launch_wgrad1x1(const void* x, int x_cs, int Cin, const void* dy, int dy_cs, int Cout, int N, int64_t V, float* dw, float* colsum,

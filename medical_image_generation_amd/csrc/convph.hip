@@ -53,10 +53,18 @@ int launchph(ConvArgs a, int ntiles, int ny, hipStream_t st) {
 // A block owns one (32 kernel-out, 16 kernel-in) block: its 32 x 16 x 27 source weights are read once, coalesced (rows of 432 resp.
 // 864 contiguous floats), into LDS and all 64 (phase, tap) fragments are summed from there -- the per-fragment gather from global
 // memory (8 floats per lane at a 108-byte stride, up to 8 taps each) took 150 us for a 256 -> 256 layer, more than the kernel it feeds.
-__global__ void __launch_bounds__(256) k_pack_phase(const float* __restrict__ w, u32x4* __restrict__ out, const unsigned* __restrict__ masks,
-                                                    int NCB, int nchunks, int Ko, int Ki, int Co_t, int Ci_t, int tr) {
+// jobs: every phase side of a network in ONE launch (blockIdx.x runs over the jobs' blocks; 12 launches of ~17 us each were 0.2 ms / step)
+__global__ void __launch_bounds__(256) k_pack_phase(const PhasePackJob* __restrict__ jobs, int njobs) {
   extern __shared__ float sm[];
-  const int kb = blockIdx.x / (nchunks * 2), kk = blockIdx.x % (nchunks * 2);
+  int ji = 0;
+  while (ji + 1 < njobs && (int)blockIdx.x >= jobs[ji + 1].block0) ++ji;
+  const PhasePackJob jb = jobs[ji];
+  const float* __restrict__ w = jb.w;
+  u32x4* __restrict__ out = (u32x4*)jb.out;
+  const unsigned* __restrict__ masks = jb.masks;
+  const int NCB = jb.NCB, nchunks = jb.nchunks, Ko = jb.Ko, Ki = jb.Ki, Co_t = jb.Co_t, Ci_t = jb.Ci_t, tr = jb.tr;
+  const int bx = blockIdx.x - jb.block0;
+  const int kb = bx / (nchunks * 2), kk = bx % (nchunks * 2);
   const int y = kb / NCB, cb = kb % NCB, ch = kk >> 1, ks = kk & 1;
   const int ko0 = kb * 32, ki0 = kk * 16;
   const int rows = tr ? 16 : 32, ni = tr ? 32 : 16;         // torch rows (out channels) / in channels of the block
@@ -108,18 +116,18 @@ int mi_launch_convph(const ConvArgs& a, int NCB, int mode, int ntiles, int ny, h
   return MI_ERR_BAD_ARG;
 }
 
-int mi_launch_pack_phase(const float* w, void* out, const unsigned* d_masks, int nfrags, int NCB, int nchunks, int Ko, int Ki, int Co_t, int Ci_t,
-                         int tr, hipStream_t st) {
-  if (!w || !out || !d_masks || nfrags <= 0 || nfrags % (8 * nchunks * 16 * NCB)) return MI_ERR_BAD_ARG;
-  const int ny = nfrags / (8 * nchunks * 16 * NCB);
-  const size_t lds = sizeof(float) * (size_t)(tr ? 16 * (32 * 27 + 1) : 32 * (16 * 27 + 1));
+int mi_pack_phase_blocks(int nfrags, int NCB, int nchunks) { (void)NCB; (void)nchunks; return nfrags / 64; }  // = ny * NCB * nchunks * 2
+
+int mi_launch_pack_phase(const PhasePackJob* d_jobs, int njobs, int total_blocks, hipStream_t st) {
+  if (!d_jobs || njobs <= 0 || total_blocks <= 0) return MI_ERR_BAD_ARG;
+  const size_t lds = sizeof(float) * (size_t)(16 * (32 * 27 + 1) > 32 * (16 * 27 + 1) ? 16 * (32 * 27 + 1) : 32 * (16 * 27 + 1));
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute((const void*)k_pack_phase, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(k_pack_phase, dim3(ny * NCB * nchunks * 2, 8), dim3(256), lds, st, w, (u32x4*)out, d_masks, NCB, nchunks, Ko, Ki, Co_t, Ci_t, tr);
+  hipLaunchKernelGGL(k_pack_phase, dim3(total_blocks, 8), dim3(256), lds, st, d_jobs, njobs);
   MI_CHECK_LAUNCH();
   return 0;
 }

@@ -33,6 +33,45 @@ FLASH_ATTENTION = _os.environ.get("MI_FLASH_ATTENTION", "1") == "1"
 FUSE_GN_STATS = ops.FUSE_GN_STATS
 
 
+# A/B knob, default OFF: weight gradients of the layers whose kernels cannot fill the chip on a second stream.  A conv's data gradient
+# and weight gradient only share their inputs; at the coarsest level of a batch-1 step (16^3 voxels x 256 channels: 16 tiles x 8
+# channel blocks) each is a launch of 128 single-tile workgroups on 256 CUs, so the two could run side by side (captured into the
+# hipGraph as two branches).  Measured (round 3, profiles/r03f_ab_side.log, same box, interleaved): 22.70 / 22.80 ms/step on one stream,
+# 23.35 / 23.36 with the fork for plans of <= 160 workgroups, 23.35 / 23.42 for <= 300: the fork / join edges of 14 layers cost more
+# than the overlap returns (round 2 measured the same for a fork of every layer).
+SIDE_WGRAD = _os.environ.get("MI_SIDE_WGRAD", "0") == "1"
+SIDE_MAX_WGS = int(_os.environ.get("MI_SIDE_MAX_WGS", "160"))
+_side_streams: dict = {}
+_side_pending: set = set()  # devices whose side stream has work the main stream has not waited for
+
+
+def _dev_index(device):
+    device = torch.device(device)
+    return torch.cuda.current_device() if device.index is None else device.index
+
+
+def _side_stream(device):
+    i = _dev_index(device)
+    st = _side_streams.get(i)
+    if st is None:
+        st = _side_streams[i] = torch.cuda.Stream(device=i)
+    return st
+
+
+def join_side(device):
+    """The current stream waits for everything forked onto the side stream (before anything reads a weight / bias gradient)."""
+    i = _dev_index(device)
+    if i in _side_pending:
+        torch.cuda.current_stream(i).wait_stream(_side_stream(i))
+        _side_pending.discard(i)
+
+
+def _small_grid(plan):
+    od, oh, ow = plan.out_dims if not isinstance(plan, ops.UpConvPlan) else plan.dims
+    tiles = plan.n * ((od + 3) // 4) * ((oh + 7) // 8) * ((ow + 7) // 8)
+    return od > 1 and tiles * ((max(plan.cin, plan.cout) + 31) // 32) <= SIDE_MAX_WGS
+
+
 # --------------------------------------------------------------------------------------------- parameters
 class ParamArena:
     """All parameters of a network in ONE flat fp32 buffer (+ one for gradients), in an order chosen so that tensors
@@ -138,6 +177,7 @@ class Tape:
         for fn in reversed(self.fns):
             fn()
         self.fns.clear()
+        join_side(out.device)
 
 
 class Ctx:
@@ -277,11 +317,22 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
             # column sums of dy come out of the wgrad kernel (one extra MFMA per k-step on the dY fragments it holds anyway):
             # per image into `d_addvec` (time-embedding gradient; the caller folds the rows into the bias gradient), or --
             # row pitch 0 -- summed over the batch straight into the bias gradient
-            if bias_grad_like is not None:
-                plan.wgrad(xin, dy, gw, pn, ps)
-                ops.add_f32_(ctx.g(name + ".bias"), ctx.g(bias_grad_like + ".bias"))
+            def wgrad():
+                if bias_grad_like is not None:
+                    plan.wgrad(xin, dy, gw, pn, ps)
+                    ops.add_f32_(ctx.g(name + ".bias"), ctx.g(bias_grad_like + ".bias"))
+                else:
+                    plan.wgrad(xin, dy, gw, pn, ps, colsum=d_addvec if d_addvec is not None else ctx.g(name + ".bias"))
+
+            if SIDE_WGRAD and need_dx and bias_grad_like is None and _small_grid(plan):
+                dev, side = dy.device, _side_stream(dy.device)
+                side.wait_stream(torch.cuda.current_stream(dev))  # dy (and everything before it) is ready
+                with torch.cuda.stream(side):
+                    wgrad()
+                xin.record_stream(side), dy.record_stream(side)    # (freed blocks must not be handed out again under the side kernel)
+                _side_pending.add(_dev_index(dev))
             else:
-                plan.wgrad(xin, dy, gw, pn, ps, colsum=d_addvec if d_addvec is not None else ctx.g(name + ".bias"))
+                wgrad()
             if res is not None:
                 tape.put(res, dy)
             if need_dx:

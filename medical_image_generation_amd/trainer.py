@@ -114,12 +114,14 @@ class _ArenaTrainer:
             if fns[i] is E.CUT:
                 break
             fns[i]()
+        E.join_side(self.device)  # (the cut ends a hipGraph / starts the early all-reduce: nothing may still be running beside it)
         return tape, fns[:i]
 
     def _fb_finish(self, state):
         tape, rest = state
         for fn in reversed(rest):
             fn()  # (a second CUT mark is a no-op)
+        E.join_side(self.device)
         tape.grads.clear(), tape.keep.clear()
 
     def forward_backward(self, *inputs, on_cut=None):

@@ -208,6 +208,7 @@ class _NetFn(torch.autograd.Function):
         for fn in reversed(tape.fns):
             fn()
         tape.fns.clear()
+        E.join_side(arena.grad.device)
         dx = None
         if ctx.need_dx:
             g = tape.take(ctx.extra["x_cl"])
@@ -429,6 +430,7 @@ class DiffusionModelUNet(HipModule):
         d_temb_all = ops.zero_f32_2d_(torch.empty_like(temb_all)) if grad else None  # conv1 wgrads accumulate their dy column sums here
         if grad:
             def bwd_emb():
+                E.join_side(dev)  # (weight gradients forked onto the side stream wrote into d_temb_all)
                 # d_temb_all holds every conv1's per-image dy column sums: their batch sums are the conv1 bias gradients
                 ops.sum_rows_f32(d_temb_all, a.span([r[0] + ".conv1.conv.bias" for r in self._resnets], a.grad), accumulate=True)
                 d_se = bwd3(d_temb_all)
