@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) k_pack_phase(const PhasePackJob* __restri
   const int rho = lane & 31, h = lane >> 5;
   const int crow = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);  // conv27 row permutation: a lane's 16 accumulators = 16 consecutive channels
   const bool row_ok = ko0 + crow < Ko;
-  for (int c = blockIdx.y * 8 + wave; c < blockIdx.y * 8 + 8; c += 4) {  // blockIdx.y = phase: its 8 taps over the 4 waves
+  for (int c = blockIdx.y * 32 + wave; c < blockIdx.y * 32 + 32; c += 4) {  // blockIdx.y = half of the phases: 32 (phase, tap) over the 4 waves
     const int pc = c >> 3, t = c & 7;
     const unsigned m = masks[c];
     F8 v;
@@ -127,7 +127,7 @@ int mi_launch_pack_phase(const PhasePackJob* d_jobs, int njobs, int total_blocks
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  hipLaunchKernelGGL(k_pack_phase, dim3(total_blocks, 8), dim3(256), lds, st, d_jobs, njobs);
+  hipLaunchKernelGGL(k_pack_phase, dim3(total_blocks, 2), dim3(256), lds, st, d_jobs, njobs);
   MI_CHECK_LAUNCH();
   return 0;
 }
