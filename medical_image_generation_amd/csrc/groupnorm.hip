@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_finalize(const float* __restrict
 }
 
 // dx = a*du + b*x + c (+ add); grid as in k_gn_apply: 40 per-channel constants stay in registers
-template <bool SILU>
+template <bool SILU, int U, bool NT>
 __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                      const float* __restrict__ scale_shift, const float* __restrict__ coef,
                                                      const bf16* __restrict__ add, int acs, const bf16* __restrict__ add2, int a2cs,
@@ -320,20 +320,20 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
   const bf16* ab = add ? add + n * V * acs + cg * 8 : nullptr;
   const bf16* a2b = add2 ? add2 + n * V * a2cs + cg * 8 : nullptr;  // second pending branch of x's gradient (e.g. a slice of d(concat))
   bf16* db = dx + n * V * dcs + cg * 8;
-  for (int64_t v = tid / C8; v < V; v += 2 * (int64_t)R) {
-    u32x4 rx[2], rg[2], ra[2], ra2[2];
+  for (int64_t v = tid / C8; v < V; v += U * (int64_t)R) {
+    u32x4 rx[U], rg[U], ra[U], ra2[U];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < U; ++k) {
       const int64_t vf = v + k * (int64_t)R, vk = rev ? V - 1 - vf : vf;  // rev: back to front (see k_gn_apply)
       if (vf < V) {
         rx[k] = *(const u32x4*)(xb + vk * xcs);
-        rg[k] = *(const u32x4*)(gb + vk * gcs);
-        if (ab) ra[k] = *(const u32x4*)(ab + vk * acs);
-        if (a2b) ra2[k] = *(const u32x4*)(a2b + vk * a2cs);
+        rg[k] = NT ? __builtin_nontemporal_load((const u32x4*)(gb + vk * gcs)) : *(const u32x4*)(gb + vk * gcs);
+        if (ab) ra[k] = NT ? __builtin_nontemporal_load((const u32x4*)(ab + vk * acs)) : *(const u32x4*)(ab + vk * acs);
+        if (a2b) ra2[k] = NT ? __builtin_nontemporal_load((const u32x4*)(a2b + vk * a2cs)) : *(const u32x4*)(a2b + vk * a2cs);
       }
     }
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < U; ++k) {
       const int64_t vf = v + k * (int64_t)R, vk = rev ? V - 1 - vf : vf;
       if (vf >= V) break;
       F8 fx = unpack8(rx[k]), fg = unpack8(rg[k]), o;
@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
 #pragma unroll
         for (int j = 0; j < 8; ++j) o.v[j] += fa.v[j];
       }
-      *(u32x4*)(db + vk * dcs) = pack8(o);
+      if (NT) __builtin_nontemporal_store(pack8(o), (u32x4*)(db + vk * dcs));
+      else *(u32x4*)(db + vk * dcs) = pack8(o);
     }
   }
 }
@@ -449,7 +450,16 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(N * G), dim3(256), sizeof(float) * 2 * (size_t)(C / G), st, (const float*)workspace, chunks, C,
                      G, V, gamma, mean_rstd, coef, dgamma, dbeta);
   int64_t grid = apply_grid(V * (C / 8), C / 8, N);
-  auto ka = silu ? k_gn_bwd_apply<true> : k_gn_bwd_apply<false>;
+  // MI_GN_VARIANT (A/B; bit 0 = 4 pieces in flight per stream instead of 2, bit 1 = non-temporal loads of the streams this pass reads for
+  // the last time (g, the pending gradient branches) and non-temporal stores of dx).  Measured round 3, same box, interleaved
+  // (profiles/r03i_ab_gn_variant.log): 22.96 ms/step with 0, 23.03 with 1, 22.75 with 2 (the default), 22.87 with 3; mi_gn_bwd at
+  // 32 ch x 128^3 back to back 132.8 / 142.0 / 124.4 / 129.8 us.  The same hints on the forward apply pass and on the backward's partial
+  // pass measured within noise (profiles/r03i_ab_gn_nt2.log) and were not kept.
+  static const int variant = [] { const char* e = getenv("MI_GN_VARIANT"); return e ? atoi(e) : 2; }();
+  auto ka = silu ? k_gn_bwd_apply<true, 2, false> : k_gn_bwd_apply<false, 2, false>;
+  if (variant == 1) ka = silu ? k_gn_bwd_apply<true, 4, false> : k_gn_bwd_apply<false, 4, false>;
+  else if (variant == 2) ka = silu ? k_gn_bwd_apply<true, 2, true> : k_gn_bwd_apply<false, 2, true>;
+  else if (variant == 3) ka = silu ? k_gn_bwd_apply<true, 4, true> : k_gn_bwd_apply<false, 4, true>;
   hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift, coef,
                      (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V, gn_sweep() & 1);
   MI_CHECK_LAUNCH();
