@@ -69,6 +69,14 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
               const float* scale_shift, const float* mean_rstd, int silu, const void* add, int add_cstride, const void* add2, int add2_cstride,
               void* dx, int dx_cstride, float* dgamma, float* dbeta, float* coef, void* workspace, int64_t workspace_bytes, hipStream_t stream);
 
+/* mi_gn_bwd in two launches instead of three: the partial pass adds its block totals (sum du, sum du x per channel) to `sums_zeroed`
+ * -- [N][C][2] fp64, ZERO on entry (the caller takes it from a buffer it clears once per step) -- with hardware fp64 atomics, and the
+ * apply pass derives the per-(image, group) coefficients and the gamma / beta gradients from those sums itself: no finalize launch in
+ * the dependency chain of every norm.  Same results as mi_gn_bwd up to the summation order of the block totals (fp64). */
+int mi_gn_bwd_fused(const void* g, int g_cstride, const void* x, int x_cstride, int N, int64_t V, int C, int G, const float* gamma,
+                    const float* scale_shift, const float* mean_rstd, int silu, const void* add, int add_cstride, const void* add2,
+                    int add2_cstride, void* dx, int dx_cstride, float* dgamma, float* dbeta, double* sums_zeroed, hipStream_t stream);
+
 /* ---- aten::convolution / convolution_backward: every Convolution(conv_only=True) -> nn.Conv{2,3}d, UNet:510,557,630,650,664,
  *      1820,1935; AEKL:67-86,121,158-187,372,454,523,606,723-749.  Per-axis (kernel,stride,padding) in {(3,1,1),(3,2,1),(1,1,0)}
  *      (the only ones the reference's planner emits, configuration.py:751-797); anything else -> MI_ERR_UNSUPPORTED. ------------ */

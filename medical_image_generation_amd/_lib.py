@@ -34,6 +34,7 @@ _SIGS = {
     "mi_gn_stats_from_partial": [_p, _i, _i, _p, _i, _i, _i, _l, _i, _f, _p, _p, _p, _p, _p],
     "mi_gn_apply": [_p, _i, _p, _p, _i, _i, _l, _i, _i, _p],
     "mi_gn_bwd": [_p, _i, _p, _i, _i, _l, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p, _l, _p],
+    "mi_gn_bwd_fused": [_p, _i, _p, _i, _i, _l, _i, _i, _p, _p, _p, _i, _p, _i, _p, _i, _p, _i, _p, _p, _p, _p],
     "mi_conv_plan_create": [C.POINTER(_p), _i, _i, _i, _i, _i, _i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)],
     "mi_upconv_plan_create": [C.POINTER(_p), _i, _i, _i, _i, _i, _i],
     "mi_conv_plan_destroy": [_p],
@@ -92,7 +93,7 @@ _lib = None
 # Version of the C ABI this binding was written against (csrc/api.hip: mi_abi_version).  Entry points have changed their argument
 # lists under unchanged names between versions, and *.so files are not tracked by git: a stale library (or an MI_LIB_PATH pointing at
 # an old ablation build) resolves every symbol and then reads shifted arguments.  load() refuses it.
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def exported_symbols() -> list[str]:

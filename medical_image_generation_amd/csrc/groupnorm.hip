@@ -33,8 +33,10 @@ __device__ __forceinline__ void load_ss(const float* ss, int c0, float* sc, floa
 // apart in a wave, so when C8 is a power of two the voxel lanes are folded with xor-shuffles (log2(64/C8) steps) and LDS only
 // sees one row per wave; otherwise every row goes through LDS.
 // out: this image's [C][chunks][2] slab -- chunk-fastest, so the finish kernels read each channel's partials as one contiguous run
+// sums64 (mi_gn_bwd_fused): instead of the chunk's slot of `out`, the block's totals are added to the image's [C][2] fp64 sums with one
+// hardware atomic per value (the consumer needs no per-chunk fold: no finalize launch).
 __device__ __forceinline__ void block_fold(float (&a)[8], float (&b)[8], float* sm, float* out, int chunks, int chunk, int C, int C8, int rows,
-                                           int r, int cg) {
+                                           int r, int cg, double* sums64 = nullptr) {
   const bool pow2 = (C8 & (C8 - 1)) == 0 && C8 <= 64;
   if (pow2) {
     for (int m = C8; m < 64; m <<= 1) {
@@ -53,8 +55,11 @@ __device__ __forceinline__ void block_fold(float (&a)[8], float (&b)[8], float* 
       }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * C; i += kT)
-      out[((int64_t)(i >> 1) * chunks + chunk) * 2 + (i & 1)] = (sm[i] + sm[2 * C + i]) + (sm[4 * C + i] + sm[6 * C + i]);
+    for (int i = threadIdx.x; i < 2 * C; i += kT) {
+      const float v = (sm[i] + sm[2 * C + i]) + (sm[4 * C + i] + sm[6 * C + i]);
+      if (sums64) unsafeAtomicAdd(sums64 + i, (double)v);
+      else out[((int64_t)(i >> 1) * chunks + chunk) * 2 + (i & 1)] = v;
+    }
   } else {
     if (r < rows) {
 #pragma unroll
@@ -67,7 +72,8 @@ __device__ __forceinline__ void block_fold(float (&a)[8], float (&b)[8], float* 
     for (int i = threadIdx.x; i < 2 * C; i += kT) {
       float acc = 0.f;
       for (int k = 0; k < rows; ++k) acc += sm[k * C * 2 + i];
-      out[((int64_t)(i >> 1) * chunks + chunk) * 2 + (i & 1)] = acc;
+      if (sums64) unsafeAtomicAdd(sums64 + i, (double)acc);
+      else out[((int64_t)(i >> 1) * chunks + chunk) * 2 + (i & 1)] = acc;
     }
   }
 }
@@ -214,7 +220,7 @@ __global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int
 template <bool SILU>
 __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                        const float* __restrict__ scale_shift, float* __restrict__ partial, int C,
-                                                       int64_t V, int64_t vchunk, int sweep) {
+                                                       int64_t V, int64_t vchunk, int sweep, double* __restrict__ sums64) {
   extern __shared__ float sm[];
   const int C8 = C / 8, rows = kT / C8;
   const int cg = threadIdx.x % C8, r = threadIdx.x / C8;
@@ -250,7 +256,8 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ 
       }
     }
   }
-  block_fold(s1, s2, sm, partial + (int64_t)n * gridDim.x * C * 2, gridDim.x, blockIdx.x, C, C8, rows, r, cg);
+  block_fold(s1, s2, sm, partial + (int64_t)n * gridDim.x * C * 2, gridDim.x, blockIdx.x, C, C8, rows, r, cg,
+             sums64 ? sums64 + (int64_t)n * C * 2 : nullptr);
 }
 
 // per (n, g): coefficients of dx = a*du + b*x + c per channel, and the affine-parameter gradients
@@ -303,14 +310,52 @@ template <bool SILU, int U, bool NT>
 __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                      const float* __restrict__ scale_shift, const float* __restrict__ coef,
                                                      const bf16* __restrict__ add, int acs, const bf16* __restrict__ add2, int a2cs,
-                                                     bf16* __restrict__ dx, int dcs, int C8, int64_t V, int rev) {
+                                                     bf16* __restrict__ dx, int dcs, int C8, int64_t V, int rev,
+                                                     const double* __restrict__ sums64, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean_rstd, int G, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
   const int C = C8 * 8;
   const int tid = blockIdx.x * kT + threadIdx.x;
   const int cg = tid % C8, R = gridDim.x * kT / C8;
   const int64_t n = blockIdx.y;
   float sc[8], sh[8], ca[8], cb[8], cc[8];
   load_ss(scale_shift + n * C * 2, cg * 8, sc, sh);
-  {
+  if (sums64) {
+    // mi_gn_bwd_fused: what k_gn_bwd_finalize computes per (n, group), recomputed here by every thread for the groups its channel octet
+    // touches, from the image's [C][2] fp64 sums (sum du, sum du x) -- a few dozen L2 loads per thread instead of a launch of G blocks
+    // in the dependency chain of every norm (51 launches of ~9 us per C4 step)
+    const int cpg = C / G;
+    const double m = (double)V * cpg;
+    const double* sn = sums64 + n * C * 2;
+    int gprev = -1;
+    float b = 0.f, c0 = 0.f, rstd = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j, gi = c / cpg;
+      if (gi != gprev) {  // (channels of an octet are consecutive: its groups come in order)
+        gprev = gi;
+        const float mean = mean_rstd[(n * G + gi) * 2];
+        rstd = mean_rstd[(n * G + gi) * 2 + 1];
+        double m1 = 0.0, m2 = 0.0;
+        for (int i = 0; i < cpg; ++i) {
+          const int ci = gi * cpg + i;
+          const double s1 = sn[2 * ci], s2 = sn[2 * ci + 1];
+          m1 += (double)gamma[ci] * s1;
+          m2 += (double)gamma[ci] * ((double)rstd * (s2 - (double)mean * s1));
+        }
+        m1 /= m; m2 /= m;
+        b = (float)(-(double)rstd * rstd * m2);
+        c0 = (float)((double)rstd * rstd * m2 * mean - (double)rstd * m1);
+      }
+      ca[j] = rstd * gamma[c]; cb[j] = b; cc[j] = c0;
+      if (tid / C8 == 0) {  // one thread per (image, octet): the affine-parameter gradients of its channels
+        const float mean = mean_rstd[(n * G + gi) * 2];
+        const double s1 = sn[2 * c], s2 = sn[2 * c + 1];
+        if (dbeta) atomicAdd(dbeta + c, (float)s1);
+        if (dgamma) atomicAdd(dgamma + c, (float)((double)rstd * (s2 - (double)mean * s1)));
+      }
+    }
+  } else {
     const float* cf = coef + (n * C + cg * 8) * 3;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ca[j] = cf[3 * j]; cb[j] = cf[3 * j + 1]; cc[j] = cf[3 * j + 2]; }
@@ -446,7 +491,7 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   int rows = kT / (C / 8);
   auto kp = silu ? k_gn_bwd_partial<true> : k_gn_bwd_partial<false>;
   hipLaunchKernelGGL(kp, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride, (const bf16*)x,
-                     x_cstride, scale_shift, (float*)workspace, C, V, vc, gn_sweep() & 1);
+                     x_cstride, scale_shift, (float*)workspace, C, V, vc, gn_sweep() & 1, (double*)nullptr);
   hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(N * G), dim3(256), sizeof(float) * 2 * (size_t)(C / G), st, (const float*)workspace, chunks, C,
                      G, V, gamma, mean_rstd, coef, dgamma, dbeta);
   int64_t grid = apply_grid(V * (C / 8), C / 8, N);
@@ -461,7 +506,33 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   else if (variant == 2) ka = silu ? k_gn_bwd_apply<true, 2, true> : k_gn_bwd_apply<false, 2, true>;
   else if (variant == 3) ka = silu ? k_gn_bwd_apply<true, 4, true> : k_gn_bwd_apply<false, 4, true>;
   hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift, coef,
-                     (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V, gn_sweep() & 1);
+                     (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V, gn_sweep() & 1,
+                     (const double*)nullptr, (const float*)nullptr, (const float*)nullptr, G, (float*)nullptr, (float*)nullptr);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+int mi_gn_bwd_fused(const void* g, int g_cstride, const void* x, int x_cstride, int N, int64_t V, int C, int G, const float* gamma,
+                    const float* scale_shift, const float* mean_rstd, int silu, const void* add, int add_cstride, const void* add2,
+                    int add2_cstride, void* dx, int dx_cstride, float* dgamma, float* dbeta, double* sums_zeroed, hipStream_t st) {
+  if (bad_c(C, G) || N <= 0 || V <= 0 || (x_cstride & 7) || (g_cstride & 7) || (dx_cstride & 7) || (add && (add_cstride & 7)) ||
+      (add2 && (!add || (add2_cstride & 7))) || !sums_zeroed || !gamma || !mean_rstd)
+    return MI_ERR_BAD_ARG;
+  int64_t vc = pick_vchunk(V);
+  int chunks = (int)((V + vc - 1) / vc);
+  int rows = kT / (C / 8);
+  auto kp = silu ? k_gn_bwd_partial<true> : k_gn_bwd_partial<false>;
+  hipLaunchKernelGGL(kp, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride, (const bf16*)x,
+                     x_cstride, scale_shift, (float*)nullptr, C, V, vc, 0, sums_zeroed);
+  int64_t grid = apply_grid(V * (C / 8), C / 8, N);
+  static const int variant = [] { const char* e = getenv("MI_GN_VARIANT"); return e ? atoi(e) : 2; }();
+  auto ka = silu ? k_gn_bwd_apply<true, 2, false> : k_gn_bwd_apply<false, 2, false>;
+  if (variant == 1) ka = silu ? k_gn_bwd_apply<true, 4, false> : k_gn_bwd_apply<false, 4, false>;
+  else if (variant == 2) ka = silu ? k_gn_bwd_apply<true, 2, true> : k_gn_bwd_apply<false, 2, true>;
+  else if (variant == 3) ka = silu ? k_gn_bwd_apply<true, 4, true> : k_gn_bwd_apply<false, 4, true>;
+  hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift,
+                     (const float*)nullptr, (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V, 0,
+                     (const double*)sums_zeroed, gamma, mean_rstd, G, dgamma, dbeta);
   MI_CHECK_LAUNCH();
   return 0;
 }

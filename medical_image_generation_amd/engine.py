@@ -31,6 +31,12 @@ FUSE_PROLOGUE = _os.environ.get("MI_FUSE_PROLOGUE", "0") == "1"
 FLASH_ATTENTION = _os.environ.get("MI_FLASH_ATTENTION", "1") == "1"
 # GroupNorm statistics from the per-channel sums the producing conv's epilogue emits (no statistics pass over the tensor)
 FUSE_GN_STATS = ops.FUSE_GN_STATS
+# A/B knob, default OFF: GroupNorm backward in two launches (partial sums by fp64 atomics into a per-pass zeroed buffer, coefficients
+# derived inside the apply pass: mi_gn_bwd_fused) instead of three.  It removes the 51 finalize launches of a C4 step (~9 us each) and
+# is SLOWER: 22.46 -> 23.47 ms/step (round 3, profiles/r03k_ab_gn_fused.log, same box, interleaved) -- 1024 blocks adding to the same
+# 64 addresses serialise at the memory side for about as long as the finalize launch took, and every apply thread now starts with a
+# dependent L2 round trip for its coefficients.
+GN_BWD_FUSED = _os.environ.get("MI_GN_BWD_FUSED", "0") == "1"
 
 
 # A/B knob, default OFF: weight gradients of the layers whose kernels cannot fill the chip on a second stream.  A conv's data gradient
@@ -196,6 +202,21 @@ class Ctx:
         # CPython reuses ids), so every lookup checks that the weak reference still IS the tensor asked about.
         self.sums = {}
         self.cat_parts = {}
+        self._z64 = None   # zeroed fp64 scratch of this pass (zeros64): cleared by ONE fill, handed out in slices
+        self._z64_off = 0
+
+    def zeros64(self, numel, device):
+        """A zeroed fp64 slice for a kernel that accumulates with atomics (the fused GroupNorm backward): carved from a buffer that one
+        fill per pass clears, so that no norm needs a zero-fill node of its own.  None when GN_BWD_FUSED is off."""
+        if not GN_BWD_FUSED:
+            return None
+        numel = (numel + 31) // 32 * 32
+        if self._z64 is None or self._z64_off + numel > self._z64.numel():
+            self._z64 = torch.zeros(max(1 << 17, numel), dtype=torch.float64, device=device)  # 1 MiB: ~130 norms of 256 channels x batch 2
+            self._z64_off = 0
+        out = self._z64[self._z64_off:self._z64_off + numel]
+        self._z64_off += numel
+        return out
 
     def sums_of(self, x):
         ent = self.sums.get(id(x))
@@ -340,7 +361,7 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
                 if norm is not None:
                     other, other2 = tape.take2(x)
                     dx = ops.gn_bwd(g, x, norm, ctx.p(norm.name + ".weight"), silu, ctx.g(norm.name + ".weight"),
-                                    ctx.g(norm.name + ".bias"), add=other, add2=other2)
+                                    ctx.g(norm.name + ".bias"), add=other, add2=other2, sums=ctx.zeros64(2 * x.shape[0] * x.shape[-1], x.device))
                     tape.grads[id(x)] = dx
                     tape.keep.append(x)
                 else:
@@ -429,7 +450,7 @@ def gn_act(ctx: Ctx, x, st, silu):
                 return
             other, other2 = tape.take2(x)
             dx = ops.gn_bwd(g, x, st, ctx.p(st.name + ".weight"), silu, ctx.g(st.name + ".weight"), ctx.g(st.name + ".bias"), add=other,
-                            add2=other2)
+                            add2=other2, sums=ctx.zeros64(2 * x.shape[0] * x.shape[-1], x.device))
             tape.grads[id(x)] = dx
             tape.keep.append(x)
 
@@ -589,7 +610,8 @@ def _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy,
     dxn = torch.empty(x.shape, dtype=BF16, device=dev)
     _gemm(dqkv, 3 * c, 0, 0, wqkv_t, 3 * c, 0, 0, dxn, c, 0, 0, b * s, c, 3 * c, 1, 1)
     other = tape.take(x)
-    dx = ops.gn_bwd(dxn, x, st, ctx.p(pre + "norm.weight"), False, ctx.g(pre + "norm.weight"), ctx.g(pre + "norm.bias"), add=dy, add2=other)
+    dx = ops.gn_bwd(dxn, x, st, ctx.p(pre + "norm.weight"), False, ctx.g(pre + "norm.weight"), ctx.g(pre + "norm.bias"), add=dy, add2=other,
+                    sums=ctx.zeros64(2 * x.shape[0] * x.shape[-1], x.device))
     tape.grads[id(x)] = dx
     tape.keep.append(x)
 

@@ -105,6 +105,16 @@ def test_groupnorm_fwd_bwd(ops, shape, groups, silu):
     check(cf(dx), xr.grad + other + other2, 1.5e-2, "gn dx")
     check(dgamma.cpu(), gr.grad, 1e-2, "gn dgamma")
     check(dbeta.cpu(), br.grad, 1e-2, "gn dbeta")
+    # the two-launch form (fp64 atomic sums, coefficients derived inside the apply pass): the same dx bit for bit up to the summation
+    # order of the block totals, the same parameter gradients
+    dgamma2, dbeta2 = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    sums = torch.zeros(2 * shape[0] * c, dtype=torch.float64, device=dev)
+    dx2 = ops.gn_bwd(cl(g), xc, st, gamma.to(dev), silu, dgamma2, dbeta2, add=cl(other), add2=cl(other2), sums=sums)
+    check(cf(dx2), xr.grad + other + other2, 1.5e-2, "gn dx (fused)")
+    assert float((dx2.float() - dx.float()).abs().max()) <= 2e-2 * float(dx.float().abs().max())
+    assert float((dx2 != dx).float().mean()) <= 1e-3, "more than rounding flips between the two forms"
+    check(dgamma2.cpu(), gr.grad, 1e-2, "gn dgamma (fused)")
+    check(dbeta2.cpu(), br.grad, 1e-2, "gn dbeta (fused)")
 
 
 @pytest.mark.parametrize("m,n,k,z", [(128, 128, 64, 1), (300, 200, 96, 2), (5, 512, 128, 1), (4096, 64, 4096, 2), (64, 70, 8, 3)])
