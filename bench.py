@@ -38,7 +38,7 @@ def kernel_source_hash():
     """sha256 over the conv kernel sources: ties a PMC measurement to the binary it was taken on."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("conv.hip", "conv27.hip", "conv_common.h", "common.h"):
+    for f in ("conv.hip", "conv27.hip", "conv27_kernel.h", "conv_common.h", "common.h"):
         with open(os.path.join(ROOT, "medical_image_generation_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

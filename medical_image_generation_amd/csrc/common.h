@@ -101,3 +101,16 @@ static inline hipError_t mi_zero_fill_f32(float* x, int64_t ld, int rows, int co
   hipLaunchKernelGGL(k_zero_f32_2d, dim3(grid), dim3(256), 0, st, x, ld, rows, cols);
   return hipGetLastError();
 }
+
+// Ablation knobs (MI_C27_DBG, MI_CPH_DBG, MI_WGRAD_DBG, MI_IGEMM_DBG) switch parts of a kernel off and make it compute GARBAGE: they are
+// read in the diagnostic builds only (`make diag` / `make phdiag`: -DMI_DIAG_KNOBS); the shipped library ignores them.
+#include <stdlib.h>
+static inline int mi_diag_knob(const char* name) {
+#ifdef MI_DIAG_KNOBS
+  const char* v = getenv(name);
+  return v ? atoi(v) : 0;
+#else
+  (void)name;
+  return 0;
+#endif
+}

@@ -1819,7 +1819,7 @@ int launch_igemm(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   const int hv = a.g.HD * a.g.HH * a.g.HW;
   const int np = (hv * 4 + 255) / 256;
   a.ntiles = ntiles;
-  static const int dbg = env_int("MI_IGEMM_DBG", 0);
+  static const int dbg = mi_diag_knob("MI_IGEMM_DBG");
   a.dbg = dbg;
   // persistent grid: ~2 workgroups per CU in total, a multiple of 8 per cout group (one slot set per XCD residue class)
   int gx = (256 * WPS / ny + 7) / 8 * 8;
@@ -2532,7 +2532,7 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
   w.nsplit = P->wg_nsplit;
   static const int contig_env = env_int("MI_WGRAD_CONTIG", 1);
   w.contig = contig_env && (w.ntiles % 8 == 0) && (w.nsplit % 8 == 0) && w.nsplit <= w.ntiles;
-  static const int dbg = env_int("MI_WGRAD_DBG", 0);
+  static const int dbg = mi_diag_knob("MI_WGRAD_DBG");
   w.dbg = dbg;
   w.colsum = dy_colsum; w.colsum_stride = dy_colsum_stride;
   static const int cs_slab = env_int("MI_CS_SLAB", 1);

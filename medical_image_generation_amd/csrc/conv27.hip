@@ -42,8 +42,8 @@ template <int NCB, int FLIP>
 int launch27(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   using KK = K<NCB, 0>;
   a.ntiles = ntiles;
-  static const char* dbg_env = getenv("MI_C27_DBG");
-  a.dbg = dbg_env ? atoi(dbg_env) : 0;
+  static const int dbg = mi_diag_knob("MI_C27_DBG");
+  a.dbg = dbg;
   const int gx = mi_conv27_grid_x(ntiles, ny);
   if (a.stats && a.stats_chunks != 4 * gx) return MI_ERR_BAD_ARG;
   auto kern = k_conv27<NCB, FLIP>;

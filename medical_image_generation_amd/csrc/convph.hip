@@ -30,8 +30,8 @@ template <int NCB, int MODE>
 int launchph(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   using KK = K<NCB, MODE>;
   a.ntiles = ntiles;
-  static const char* dbg_env = getenv("MI_CPH_DBG");  // ablation knob: 1 = no store epilogue (results are garbage)
-  a.dbg = dbg_env ? atoi(dbg_env) & 1 : 0;
+  static const int dbg = mi_diag_knob("MI_CPH_DBG") & 1;  // ablation knob: 1 = no store epilogue (results are garbage)
+  a.dbg = dbg;
   a.stats = nullptr; a.stats_chunks = 0;
   const int gx = mi_conv27_grid_x(ntiles, ny);
   auto kern = k_convph<NCB, MODE>;
