@@ -195,6 +195,31 @@ int mi_avgpool_bwd(const void* dy, void* dx, int N, int D, int H, int W, int C, 
 int mi_crop_pad(const void* src, int src_is_f16, int C, int D, int H, int W, const int lo[3], float* out, int oD, int oH, int oW,
                 float pad_value, int flip_mask, float scale, int clamp01, hipStream_t stream);
 
+/* ---- PatchDiscriminator path of the autoencoder's GAN step (train_autoencoder.py:371-397 train_discriminator_step, :416-423 the
+ * generator's adversarial term, :600 `PatchDiscriminator(**discriminator_params)`; third-party `generative` classes: PARITY UNPINNED).
+ * Its k4 convs (stride 2 / 1, padding 1) are lowered to mi_gemm_nt_bf16 through an explicit patch matrix:
+ *   patches [N*Do*Ho*Wo][k^3 * C] bf16 (tap-major, zero outside the tensor), y = patches . W2^T, dx = fold(dy . W2), dW2 = dy^T . patches.
+ * BatchNorm (training mode) = mi_gn_stats / mi_gn_apply / mi_gn_bwd with G = C on the [1][N*V][C] view, activation code 2 = LeakyReLU(0.2)
+ * (the `silu` argument of those entry points: 0 none, 1 SiLU, 2 LeakyReLU(0.2)). -------------------------------------------------- */
+int mi_im2col3d(const void* x, int x_cstride, void* patches, int N, int D, int H, int W, int C, int k, int s, int p, hipStream_t stream);
+int mi_col2im3d(const void* dpatches, void* dx, int dx_cstride, int N, int D, int H, int W, int C, int k, int s, int p, hipStream_t stream);
+/* torch weight [Cout][Cin][taps] fp32 -> w2 [Cout_padded][taps * Cin] bf16 (rows >= Cout zero) and its transpose w2t */
+int mi_disc_pack_weights(const float* w, void* w2, void* w2t, int Cout, int Cout_padded, int Cin, int taps, hipStream_t stream);
+/* dw [Cout][Cin][taps] += dw2 [>= Cout][taps * Cin] */
+int mi_disc_wgrad_unpack(const float* dw2, float* dw, int Cout, int Cin, int taps, hipStream_t stream);
+/* nn.LeakyReLU(slope) (+backward) on n bf16 elements, n % 8 == 0 */
+int mi_leaky_relu_fwd(const void* x, void* y, int64_t n, float slope, hipStream_t stream);
+int mi_leaky_relu_bwd(const void* x, const void* dy, void* dx, int64_t n, float slope, hipStream_t stream);
+/* PatchAdversarialLoss(criterion="least_squares") (train_autoencoder.py:41, 380-383, 418-419) on channel 0 of logits [nvox][cs] bf16:
+ * a = LeakyReLU(act_slope)(logit) (upstream: 0.05 unless no_activation_leastsq; 1 = none), *loss += weight * mean((a - target)^2);
+ * dlogits (same pitch, may be NULL): channel 0 = the gradient, channels 1.. = 0 */
+int mi_ls_gan_loss(const void* logits, int cs, int64_t nvox, float target, float act_slope, void* dlogits, float* loss, float weight,
+                   hipStream_t stream);
+/* nn.BatchNorm buffers after a training-mode forward: running = (1 - momentum) running + momentum batch (variance unbiased);
+ * mean_rstd: [C][2] from mi_gn_stats on the [1][N*V][C] view (count = N*V); num_batches_tracked (int64, may be NULL) += 1 */
+int mi_bn_running_update(const float* mean_rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked, int C, float eps,
+                         float momentum, int64_t count, hipStream_t stream);
+
 /* ---- train-step glue: scheduler.add_noise (T-LDM:160), F.mse_loss (+backward) (T-LDM:169, T-DDPM:192) ------------------- */
 int mi_qsample(const float* x0, const float* noise, const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod,
                const int64_t* timesteps, const float* cond, int cond_channels, void* out, float* velocity, int N, int C, int64_t V,

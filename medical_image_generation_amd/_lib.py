@@ -74,6 +74,14 @@ _SIGS = {
     "mi_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_crop_pad": [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p],
+    "mi_im2col3d": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "mi_col2im3d": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
+    "mi_disc_pack_weights": [_p, _p, _p, _i, _i, _i, _i, _p],
+    "mi_disc_wgrad_unpack": [_p, _p, _i, _i, _i, _p],
+    "mi_leaky_relu_fwd": [_p, _p, _l, _f, _p],
+    "mi_leaky_relu_bwd": [_p, _p, _p, _l, _f, _p],
+    "mi_ls_gan_loss": [_p, _i, _l, _f, _f, _p, _p, _f, _p],
+    "mi_bn_running_update": [_p, _p, _p, _p, _i, _f, _f, _l, _p],
     "mi_qsample": [_p, _p, _p, _p, _p, _p, _i, _p, _p, _i, _i, _l, _i, _p],
     "mi_ddpm_step": [_p, _p, _p, _p, _p, _p, _i, _i, _i, _l, _i, _p],
     "mi_mse_fwd_bwd": [_p, _p, _p, _p, _i, _i, _l, _f, _p],
@@ -93,7 +101,7 @@ _lib = None
 # Version of the C ABI this binding was written against (csrc/api.hip: mi_abi_version).  Entry points have changed their argument
 # lists under unchanged names between versions, and *.so files are not tracked by git: a stale library (or an MI_LIB_PATH pointing at
 # an old ablation build) resolves every symbol and then reads shifted arguments.  load() refuses it.
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def exported_symbols() -> list[str]:

@@ -16,6 +16,20 @@ namespace {
 
 constexpr int kT = 256;
 
+// activation behind the affine: 0 none, 1 SiLU (UNet / AEKL), 2 LeakyReLU(0.2) (the PatchDiscriminator's BatchNorm layers)
+template <int ACT>
+__device__ __forceinline__ float act_f(float u) {
+  if constexpr (ACT == 1) return silu_f(u);
+  else if constexpr (ACT == 2) return u > 0.f ? u : 0.2f * u;
+  else return u;
+}
+template <int ACT>
+__device__ __forceinline__ float act_grad_f(float u) {
+  if constexpr (ACT == 1) return silu_grad_f(u);
+  else if constexpr (ACT == 2) return u > 0.f ? 1.f : 0.2f;
+  else return 1.f;
+}
+
 struct Geo {
   int C8;    // channel groups of 8
   int rows;  // voxel lanes per block = kT / C8
@@ -183,7 +197,7 @@ __global__ void __launch_bounds__(256) k_gn_finalize(const float* __restrict__ p
 // y = act(x * scale + shift).  grid = (gx, N) with gx * kT a multiple of C8: a thread keeps ONE channel octet of ONE image for its
 // whole loop, so its 16 scale / shift values stay in registers, the loop has no integer division, and 4 independent 16-byte loads
 // are in flight per lane.
-template <bool SILU>
+template <int ACT>
 __global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int xcs, const float* __restrict__ scale_shift,
                                                  bf16* __restrict__ y, int ycs, int C8, int64_t V, int rev) {
   const int C = C8 * 8;
@@ -209,7 +223,7 @@ __global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float u = f.v[j] * sc[j] + sh[j];
-        f.v[j] = SILU ? silu_f(u) : u;
+        f.v[j] = act_f<ACT>(u);
       }
       *(u32x4*)(yb + (v + k * (int64_t)R) * ys) = pack8(f);
     }
@@ -217,7 +231,7 @@ __global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int
 }
 
 // backward partials: (sum du, sum du*x) per (n, chunk, c);  du = g * silu'(x*scale+shift)  (or g when !silu)
-template <bool SILU>
+template <int ACT>
 __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                        const float* __restrict__ scale_shift, float* __restrict__ partial, int C,
                                                        int64_t V, int64_t vchunk, int sweep, double* __restrict__ sums64) {
@@ -249,7 +263,7 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           float du = fg.v[j];
-          if (SILU) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
+          if (ACT) du *= act_grad_f<ACT>(fx.v[j] * sc[j] + sh[j]);
           s1[j] += du;
           s2[j] += du * fx.v[j];
         }
@@ -306,7 +320,7 @@ __global__ void __launch_bounds__(256) k_gn_bwd_finalize(const float* __restrict
 }
 
 // dx = a*du + b*x + c (+ add); grid as in k_gn_apply: 40 per-channel constants stay in registers
-template <bool SILU, int U, bool NT>
+template <int ACT, int U, bool NT>
 __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                      const float* __restrict__ scale_shift, const float* __restrict__ coef,
                                                      const bf16* __restrict__ add, int acs, const bf16* __restrict__ add2, int a2cs,
@@ -385,7 +399,7 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float du = fg.v[j];
-        if (SILU) du *= silu_grad_f(fx.v[j] * sc[j] + sh[j]);
+        if (ACT) du *= act_grad_f<ACT>(fx.v[j] * sc[j] + sh[j]);
         o.v[j] = ca[j] * du + cb[j] * fx.v[j] + cc[j];
       }
       if (ab) {
@@ -472,7 +486,8 @@ int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y,
                 hipStream_t st) {
   if (C <= 0 || (C & 7) || (x_cstride & 7) || (y_cstride & 7) || N <= 0 || V <= 0) return MI_ERR_BAD_ARG;
   int64_t grid = apply_grid(V * (C / 8), C / 8, N);
-  auto k = silu ? k_gn_apply<true> : k_gn_apply<false>;
+  if (silu < 0 || silu > 2) return MI_ERR_BAD_ARG;  // activation code: 0 none, 1 SiLU, 2 LeakyReLU(0.2)
+  auto k = silu == 1 ? k_gn_apply<1> : (silu == 2 ? k_gn_apply<2> : k_gn_apply<0>);
   hipLaunchKernelGGL(k, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)x, x_cstride, scale_shift, (bf16*)y, y_cstride, C / 8, V,
                      gn_sweep() & 2 ? 1 : 0);
   MI_CHECK_LAUNCH();
@@ -489,7 +504,8 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   int64_t vc = pick_vchunk(V);
   int chunks = (int)((V + vc - 1) / vc);
   int rows = kT / (C / 8);
-  auto kp = silu ? k_gn_bwd_partial<true> : k_gn_bwd_partial<false>;
+  if (silu < 0 || silu > 2) return MI_ERR_BAD_ARG;
+  auto kp = silu == 1 ? k_gn_bwd_partial<1> : (silu == 2 ? k_gn_bwd_partial<2> : k_gn_bwd_partial<0>);
   hipLaunchKernelGGL(kp, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride, (const bf16*)x,
                      x_cstride, scale_shift, (float*)workspace, C, V, vc, gn_sweep() & 1, (double*)nullptr);
   hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(N * G), dim3(256), sizeof(float) * 2 * (size_t)(C / G), st, (const float*)workspace, chunks, C,
@@ -501,10 +517,10 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   // 32 ch x 128^3 back to back 132.8 / 142.0 / 124.4 / 129.8 us.  The same hints on the forward apply pass and on the backward's partial
   // pass measured within noise (profiles/r03i_ab_gn_nt2.log) and were not kept.
   static const int variant = [] { const char* e = getenv("MI_GN_VARIANT"); return e ? atoi(e) : 2; }();
-  auto ka = silu ? k_gn_bwd_apply<true, 2, false> : k_gn_bwd_apply<false, 2, false>;
-  if (variant == 1) ka = silu ? k_gn_bwd_apply<true, 4, false> : k_gn_bwd_apply<false, 4, false>;
-  else if (variant == 2) ka = silu ? k_gn_bwd_apply<true, 2, true> : k_gn_bwd_apply<false, 2, true>;
-  else if (variant == 3) ka = silu ? k_gn_bwd_apply<true, 4, true> : k_gn_bwd_apply<false, 4, true>;
+  auto ka = silu == 1 ? k_gn_bwd_apply<1, 2, false> : (silu == 2 ? k_gn_bwd_apply<2, 2, false> : k_gn_bwd_apply<0, 2, false>);
+  if (variant == 1) ka = silu == 1 ? k_gn_bwd_apply<1, 4, false> : (silu == 2 ? k_gn_bwd_apply<2, 4, false> : k_gn_bwd_apply<0, 4, false>);
+  else if (variant == 2) ka = silu == 1 ? k_gn_bwd_apply<1, 2, true> : (silu == 2 ? k_gn_bwd_apply<2, 2, true> : k_gn_bwd_apply<0, 2, true>);
+  else if (variant == 3) ka = silu == 1 ? k_gn_bwd_apply<1, 4, true> : (silu == 2 ? k_gn_bwd_apply<2, 4, true> : k_gn_bwd_apply<0, 4, true>);
   hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift, coef,
                      (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V, gn_sweep() & 1,
                      (const double*)nullptr, (const float*)nullptr, (const float*)nullptr, G, (float*)nullptr, (float*)nullptr);
@@ -521,15 +537,16 @@ int mi_gn_bwd_fused(const void* g, int g_cstride, const void* x, int x_cstride, 
   int64_t vc = pick_vchunk(V);
   int chunks = (int)((V + vc - 1) / vc);
   int rows = kT / (C / 8);
-  auto kp = silu ? k_gn_bwd_partial<true> : k_gn_bwd_partial<false>;
+  if (silu < 0 || silu > 2) return MI_ERR_BAD_ARG;
+  auto kp = silu == 1 ? k_gn_bwd_partial<1> : (silu == 2 ? k_gn_bwd_partial<2> : k_gn_bwd_partial<0>);
   hipLaunchKernelGGL(kp, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride, (const bf16*)x,
                      x_cstride, scale_shift, (float*)nullptr, C, V, vc, 0, sums_zeroed);
   int64_t grid = apply_grid(V * (C / 8), C / 8, N);
   static const int variant = [] { const char* e = getenv("MI_GN_VARIANT"); return e ? atoi(e) : 2; }();
-  auto ka = silu ? k_gn_bwd_apply<true, 2, false> : k_gn_bwd_apply<false, 2, false>;
-  if (variant == 1) ka = silu ? k_gn_bwd_apply<true, 4, false> : k_gn_bwd_apply<false, 4, false>;
-  else if (variant == 2) ka = silu ? k_gn_bwd_apply<true, 2, true> : k_gn_bwd_apply<false, 2, true>;
-  else if (variant == 3) ka = silu ? k_gn_bwd_apply<true, 4, true> : k_gn_bwd_apply<false, 4, true>;
+  auto ka = silu == 1 ? k_gn_bwd_apply<1, 2, false> : (silu == 2 ? k_gn_bwd_apply<2, 2, false> : k_gn_bwd_apply<0, 2, false>);
+  if (variant == 1) ka = silu == 1 ? k_gn_bwd_apply<1, 4, false> : (silu == 2 ? k_gn_bwd_apply<2, 4, false> : k_gn_bwd_apply<0, 4, false>);
+  else if (variant == 2) ka = silu == 1 ? k_gn_bwd_apply<1, 2, true> : (silu == 2 ? k_gn_bwd_apply<2, 2, true> : k_gn_bwd_apply<0, 2, true>);
+  else if (variant == 3) ka = silu == 1 ? k_gn_bwd_apply<1, 4, true> : (silu == 2 ? k_gn_bwd_apply<2, 4, true> : k_gn_bwd_apply<0, 4, true>);
   hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift,
                      (const float*)nullptr, (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V, 0,
                      (const double*)sums_zeroed, gamma, mean_rstd, G, dgamma, dbeta);

@@ -436,3 +436,112 @@ class AETrainer(_ArenaTrainer):
             drecon = ops.add(drecon, ops.to_channels_last(g))
             self.reconstruction = rec.detach()
         return tape, recon, drecon
+
+
+class AEGANTrainer(AETrainer):
+    """The autoencoder's GAN step with BOTH networks on the HIP path (train_autoencoder.AutoEncoder.train_one_epoch, T-AE:371-435):
+
+        generator      (T-AE:406-435): recon = AE(images); loss_g = L1 + kl_weight * KL [+ extra_loss] + (adversarial: after the warm-up
+                       epochs, T-AE:416) adv_weight * LS(D(recon)[-1], real)  ->  backward through D (frozen) and the AE -> clip -> Adam
+        discriminator  (T-AE:371-397): loss_d = adv_weight * 0.5 * (LS(D(recon.detach())[-1], fake) + LS(D(images)[-1], real))
+                       ->  backward through D -> clip -> Adam (lr 5e-5, T-AE:471)
+
+    `discriminator`: medical_image_generation_amd.discriminator.PatchDiscriminator; LS = PatchAdversarialLoss("least_squares").
+    step(images, eps) runs both (the reference's order: generator, then discriminator on the same reconstruction); `adversarial`
+    switches the adversarial term and the discriminator step on (epoch >= autoencoder_warm_up_epochs).  The perceptual term needs
+    downloaded weights and stays the caller's `extra_loss`.  capture() / step_graph() replay generator and discriminator graphs."""
+
+    def __init__(self, model, discriminator, adv_weight=0.01, d_lr=5e-5, adversarial=True, **kw):
+        super().__init__(model, **kw)
+        if self.grad_accumulate_step != 1:
+            raise NotImplementedError("AEGANTrainer covers grad_accumulate_step == 1")
+        from .discriminator import PatchAdversarialLoss
+        self.D = discriminator
+        self.d_arena = discriminator.arena(self.device)
+        if self.world > 1:
+            ddp.broadcast_parameters(self.d_arena.data, 0, self.pg)
+        self.adv, self.adv_weight, self.d_lr = PatchAdversarialLoss("least_squares"), float(adv_weight), float(d_lr)
+        self.adversarial = bool(adversarial)
+        n = self.d_arena.n_trainable
+        self.d_exp_avg = torch.zeros(n, dtype=F32, device=self.device)
+        self.d_exp_avg_sq = torch.zeros(n, dtype=F32, device=self.device)
+        self.d_step_count = torch.zeros(1, dtype=F32, device=self.device)
+        self.d_sumsq = torch.zeros(1, dtype=F32, device=self.device)
+        self.gen_loss = torch.zeros(1, dtype=F32, device=self.device)   # adv_weight * LS(D(recon), real) of the last generator step
+        self.disc_loss = torch.zeros(1, dtype=F32, device=self.device)  # adv_weight * 0.5 (fake + real) of the last discriminator step
+        self.recon_cl = None
+        self._g_d = None
+
+    def _models(self):
+        return [self.model]
+
+    def _forward(self, images, eps):
+        tape, recon, drecon = super()._forward(images, eps)
+        self.recon_cl = recon
+        if self.adversarial:
+            self.gen_loss.zero_()
+            c = E.Ctx(self.d_arena, {}, grad_enabled=True)
+            logits = self.D._run(c, recon, need_dx=True, param_grads=False)[-1]  # D frozen: `requires_grad = False` (T-AE:401-402)
+            dl = self.adv.hip(logits, True, self.gen_loss, self.adv_weight)
+            c.tape.backward(logits, dl)
+            g = c.tape.take(recon)
+            c.tape.grads.clear(), c.tape.keep.clear()
+            drecon = ops.add(drecon, g)
+            ops.add_f32_(self.loss.view(1, 1), self.gen_loss.view(1, 1))
+        return tape, recon, drecon
+
+    # ---- discriminator step
+    def d_forward_backward(self, images):
+        """Gradients of loss_d into d_arena.grad (fresh), loss into self.disc_loss; uses the reconstruction of the last generator step."""
+        if self.recon_cl is None:
+            raise RuntimeError("run the generator step first (the discriminator step scores ITS reconstruction, T-AE:376)")
+        self.d_arena.grad.zero_()
+        self.disc_loss.zero_()
+        for x_cl, real in ((self.recon_cl, False), (ops.to_channels_last(images), True)):
+            c = E.Ctx(self.d_arena, {}, grad_enabled=True)
+            logits = self.D._run(c, x_cl, need_dx=False)[-1]
+            dl = self.adv.hip(logits, real, self.disc_loss, 0.5 * self.adv_weight)
+            c.tape.backward(logits, dl)
+            c.tape.grads.clear(), c.tape.keep.clear()
+
+    def d_optimizer_step(self):
+        a = self.d_arena
+        n = a.n_trainable
+        if self.world > 1:
+            ddp.GradientExchange(a.grad, 0, n, self.pg, self.bucket_elems).finish()
+        clip = self.max_grad_norm is not None and self.max_grad_norm > 0
+        if clip:
+            call("mi_sumsq_f32", ptr(a.grad), n, ptr(self.d_sumsq), 0)
+        call("mi_adam_step", ptr(a.data), ptr(a.grad), ptr(self.d_exp_avg), ptr(self.d_exp_avg_sq), n, self.d_lr, self.betas[0], self.betas[1],
+             self.eps, 0.0, 0, ptr(self.d_sumsq) if clip else None, float(self.max_grad_norm or 0.0), 1.0 / self.world, ptr(self.d_step_count))
+
+    def step(self, images, eps, last_in_epoch=False):
+        loss = super().step(images, eps)
+        if self.adversarial:
+            self.d_forward_backward(images)
+            self.d_optimizer_step()
+        return loss
+
+    def capture(self, images, eps, warmup=2):
+        super().capture(images, eps, warmup=warmup)
+        if self.adversarial:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self.d_forward_backward(self._static[0])
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self._g_d = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_d, pool=self._g_fb.pool(), capture_error_mode="thread_local"):
+                self.d_forward_backward(self._static[0])
+                if self.world <= 1:
+                    self.d_optimizer_step()
+            self._pinned.append((self.d_arena, dict(ops._ws_cache)))
+
+    def step_graph(self, images=None, eps=None):
+        loss = super().step_graph(images, eps)
+        if self._g_d is not None:
+            self._g_d.replay()
+            if self.world > 1:
+                self.d_optimizer_step()
+        return loss

@@ -87,3 +87,14 @@ def test_arena_layout_keeps_fused_tensors_adjacent():
     # statically unused tensors sit behind the trainable prefix
     assert all(a.offsets[n] >= a.n_trainable for n, _, t in net._entries if not t)
     assert all(a.offsets[n] < a.n_trainable for n, _, t in net._entries if t)
+
+
+def test_discriminator_state_dict_names_match_the_restated_upstream_module():
+    """PatchDiscriminator (third-party `generative` class, restated in oracle/disc.py: PARITY UNPINNED): same state_dict names, shapes and
+    order -- upstream checkpoints of the discriminator load."""
+    from medical_image_generation_amd.discriminator import PatchDiscriminator
+    from oracle import disc as odisc
+    kw = dict(spatial_dims=3, num_channels=64, in_channels=1, out_channels=1, num_layers_d=3)  # configuration.py:966-967
+    net, ref = PatchDiscriminator(**kw), odisc.PatchDiscriminator(**kw)
+    assert [(k, tuple(v.shape)) for k, v in net.state_dict().items()] == [(k, tuple(v.shape)) for k, v in ref.state_dict().items()]
+    net.load_state_dict(ref.state_dict())
