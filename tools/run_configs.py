@@ -1,5 +1,7 @@
 """Run the other BASELINE.json configs through the fused HIP trainer and report ms/step (sanity + scale check).
-usage: python tools/run_configs.py c2|c3a|c3b|c3b_ldm|c5|c5_ckpt [steps]
+usage: python tools/run_configs.py c2|c3a|c3a_gan|c3b|c3b_ldm|c5|c5_ckpt [steps]
+  c3a_gan: the autoencoder step AFTER the warm-up epochs -- generator step with the adversarial term through the planner's PatchDiscriminator
+           (64 base channels, 3 layers) + the discriminator step (AEGANTrainer), both networks on the HIP path
   c3b_ldm: the latent-diffusion step as train_ldm.py runs it -- no-grad AutoencoderKL.encode_stage_2_inputs of the 4 x 128^3 images
            inside the step (LDMTrainer), then the C3b UNet step on the scaled latents
   c5_ckpt: C5 with per-block activation checkpointing (BASELINE configs[4])"""
@@ -19,11 +21,11 @@ which = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 
 
-def run_c3a():
+def run_c3a(gan=False):
     """AutoencoderKL exactly as CFG:821-862 emits it for a 128^3 single-channel dataset (BASELINE configs[2], AE half):
     fused generator step (L1 + kl_weight*KL, clip 1, Adam; T-AE:411-434) replayed from a hipGraph."""
     from medical_image_generation_amd.autoencoderkl import AutoencoderKL
-    from medical_image_generation_amd.trainer import AETrainer
+    from medical_image_generation_amd.trainer import AEGANTrainer, AETrainer
     down = [[[1] * 3, [3] * 3, [1] * 3], [[2] * 3, [3] * 3, [1] * 3], [[2] * 3, [3] * 3, [1] * 3]]
     kw = dict(spatial_dims=3, in_channels=1, out_channels=1, latent_channels=8, num_res_blocks=2, num_channels=[32, 64, 128],
               attention_levels=[False] * 3, norm_num_groups=16, with_encoder_nonlocal_attn=False, with_decoder_nonlocal_attn=False,
@@ -31,7 +33,12 @@ def run_c3a():
     dev = torch.device("cuda")
     torch.manual_seed(0)
     net = AutoencoderKL(**kw).to(dev)
-    tr = AETrainer(net, lr=5e-5, kl_weight=1e-7)
+    if gan:
+        from medical_image_generation_amd.discriminator import PatchDiscriminator
+        disc = PatchDiscriminator(spatial_dims=3, in_channels=1, out_channels=1, num_channels=64, num_layers_d=3).to(dev)  # CFG:966-967
+        tr = AEGANTrainer(net, disc, adv_weight=0.01, lr=5e-5, d_lr=5e-5, kl_weight=1e-7)
+    else:
+        tr = AETrainer(net, lr=5e-5, kl_weight=1e-7)
     x = torch.rand((2, 1, 128, 128, 128), device=dev)
     eps = torch.randn((2, 8, 32, 32, 32), device=dev)
     tr.capture(x, eps)
@@ -44,13 +51,13 @@ def run_c3a():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     assert math.isfinite(float(loss)), "non-finite loss: not a measurement"
-    print(json.dumps({"config": "c3a", "ms_per_step": dt * 1e3, "voxels_per_s": 2 * 128 ** 3 / dt, "loss": float(loss),
+    print(json.dumps({"config": "c3a_gan" if gan else "c3a", "ms_per_step": dt * 1e3, "voxels_per_s": 2 * 128 ** 3 / dt, "loss": float(loss),
                       "params": sum(p.numel() for p in net.parameters()), "model_flops_per_step_survey": 1.497e13,
                       "mfma_frac": 1.497e13 / dt / 2.5e15, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
 
 
-if which == "c3a":
-    run_c3a()
+if which in ("c3a", "c3a_gan"):
+    run_c3a(gan=which == "c3a_gan")
     sys.exit(0)
 iso = lambda n: [[1] * 3] + [[2] * 3] * (n - 1)
 if which == "c2":   # 3D DDPM 96^3, batch 2 (BASELINE configs[1])
