@@ -13,63 +13,11 @@
 //   backward, q outer  : dQ^T[d,q]  += K^T[d,key]   dS^T[key,q]
 //   backward, kv outer : dV^T[dv,k] += dO^T[dv,q]   P[q,key] ,  dK^T[d,k] += Q^T[d,q] dS[q,key]   (key on the lane)
 // One workgroup = 4 waves x 32 rows; K/V (or Q/dO) tiles of 64 rows are staged through LDS by all 4 waves.
-#include "common.h"
-#include "medimgen_hip.h"
+#include "attention_common.h"
+
+using namespace mi_attn;
 
 namespace {
-
-constexpr float kLog2e = 1.4426950408889634f;
-constexpr f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-// v_exp_f32 without exp2f()'s denormal-range scaling: arguments here are <= 0 and results below 2^-126 may flush to zero
-__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-struct AttnArgs {
-  const bf16* qkv;   // [B*S][ld]
-  int ld, C, heads, S;
-  float scale;
-  const bf16* resid;  // forward: x (added to the output) or null
-  bf16* y;            // forward: [B*S][C]
-  float* lse;         // [B*heads][S], log2 domain: m + log2(l)
-  // backward
-  const bf16* dy;     // [B*S][C] gradient of the attention output (the residual branch is handled by the caller)
-  const bf16* o;      // [B*S][C] forward output WITHOUT residual is not stored; o = y - x is recomputed from y and resid
-  float* dsum;        // [B*heads][S]  D = rowsum(dO * O)
-  bf16* dqkv;         // [B*S][ld]
-  // split over the reduction axis (keys in forward / dQ, queries in dK,dV): blockIdx.z handles `tps` 64-row tiles and writes
-  // a partial result; k_attn_merge_* combine them.  nsplit == 1: results go straight to y / dqkv.
-  int nsplit, tps;
-  bf16* part;         // forward: [nsplit][B*S][C] normalised partial outputs; backward: [nsplit][B*S][3C] partial dQ | dK | dV
-  float* part_ml;     // forward: [nsplit][B*heads][S][2] running max (log2 domain) and sum of each partial
-};
-
-// 16 bytes = 8 bf16 of row `row` at element offset `col` (ld in elements); zero when row >= limit
-__device__ __forceinline__ u32x4 ld16(const bf16* base, int64_t row, int limit, int ld, int col) {
-  u32x4 z = {0u, 0u, 0u, 0u};
-  return row < limit ? *(const u32x4*)(base + row * ld + col) : z;
-}
-
-// transposed LDS read producing the A fragment of X^T for the permuted k order of an accumulator-as-B-operand product:
-// element j of lane half h <- row 16*s + 8*(j>>2) + 4*h + (j&3), column (lane & 31) of the 32-column block `cblk`
-__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int row0, int s, int cblk, int lane) {
-  typedef __attribute__((address_space(3))) bf16x4 lds_v4;
-  const int gq = lane >> 4, q = (lane >> 2) & 3, p = lane & 3, h = lane >> 5;
-  const char* a = tile + (row0 + 16 * s + 4 * h + q) * pitch + (cblk * 32 + (gq & 1) * 16 + p * 4) * 2;
-  bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)a);
-  bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(a + 8 * pitch));
-  bf16x8 f;
-  f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3];
-  f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-  return f;
-}
-// rows-as-A fragment: lane (r, h) reads 16 bytes of row r: columns ks*16 + 8h ..
-__device__ __forceinline__ bf16x8 row_frag(const char* tile, int pitch, int row0, int ks, int lane) {
-  return *(const bf16x8*)(tile + (row0 + (lane & 31)) * pitch + ks * 32 + (lane >> 5) * 16);
-}
-__device__ __forceinline__ bf16x8 pack_acc8(const f32x16& a, int s) {  // registers 8s..8s+7 -> bf16x8 (k-step s as B operand)
-  u32x4 r = {pack2(a[8 * s], a[8 * s + 1]), pack2(a[8 * s + 2], a[8 * s + 3]), pack2(a[8 * s + 4], a[8 * s + 5]),
-             pack2(a[8 * s + 6], a[8 * s + 7])};
-  return __builtin_bit_cast(bf16x8, r);
-}
 
 template <int D>
 struct Tiles {  // LDS images of a 64-row tile of two operands
@@ -506,11 +454,30 @@ bool bad(int C, int heads, int S, int B, int ld) {
 
 }  // namespace
 
+namespace mi_attn {
+void attn_merge_fwd_launch(const AttnArgs& a, int B, hipStream_t st) {
+  const int64_t rows = (int64_t)B * a.S, n = rows * (a.C / 8);
+  hipLaunchKernelGGL(k_attn_merge_fwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, a.part_ml, a.resid, a.y, a.lse, a.C, a.heads, a.S,
+                     rows, a.nsplit);
+}
+void attn_merge_bwd_launch(const AttnArgs& a, int B, hipStream_t st) {
+  const int64_t rows = (int64_t)B * a.S, n = rows * (3 * a.C / 8);
+  hipLaunchKernelGGL(k_attn_merge_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a.part, a.dqkv, a.ld, 3 * a.C, rows, a.nsplit);
+}
+void attn_dsum_launch(const AttnArgs& a, const bf16* y, const bf16* resid, int B, hipStream_t st) {
+  const int64_t rows = (int64_t)B * a.S;
+  hipLaunchKernelGGL(k_attn_dsum, dim3((int)((rows + 3) / 4)), dim3(256), 0, st, a.dy, y, resid, a.dsum, a.C, a.heads, a.S, rows);
+}
+}  // namespace mi_attn
+
 extern "C" {
 
-int mi_attn_supported(int C, int heads) { return heads > 0 && C % heads == 0 && (C / heads == 32 || C / heads == 64); }
+int mi_attn_supported(int C, int heads) {
+  return heads > 0 && C % heads == 0 && (C / heads == 32 || C / heads == 64 || attnw_supported(C, heads));
+}
 
 int64_t mi_attn_workspace_bytes(int C, int heads, int B, int S) {
+  if (attnw_supported(C, heads)) return attnw_workspace_bytes(C, heads, B, S);
   if (bad(C, heads, S, B, 3 * C)) return 0;
   int ns, tps;
   pick_split(B, heads, S, ns, tps);
@@ -520,10 +487,12 @@ int64_t mi_attn_workspace_bytes(int C, int heads, int B, int S) {
 
 int mi_attn_fwd(const void* qkv, int ld, int C, int heads, int B, int S, float scale, const void* resid, void* y, float* lse, void* ws,
                 int64_t ws_bytes, hipStream_t st) {
-  if (bad(C, heads, S, B, ld) || !qkv || !y) return MI_ERR_BAD_ARG;
+  if (!qkv || !y) return MI_ERR_BAD_ARG;
   AttnArgs a{};
   a.qkv = (const bf16*)qkv; a.ld = ld; a.C = C; a.heads = heads; a.S = S; a.scale = scale;
   a.resid = (const bf16*)resid; a.y = (bf16*)y; a.lse = lse;
+  if (attnw_supported(C, heads)) return attnw_fwd(a, B, ws, ws_bytes, st);
+  if (bad(C, heads, S, B, ld)) return MI_ERR_BAD_ARG;
   pick_split(B, heads, S, a.nsplit, a.tps);
   if (!ws || (size_t)ws_bytes < fwd_ws(C, heads, B, S, a.nsplit)) a.nsplit = 1, a.tps = (S + 63) / 64;  // no scratch: one pass over all keys
   a.part = (bf16*)ws;
@@ -531,11 +500,7 @@ int mi_attn_fwd(const void* qkv, int ld, int C, int heads, int B, int S, float s
   dim3 grid((S + 127) / 128, B * heads, a.nsplit), blk(256);
   if (C / heads == 64) hipLaunchKernelGGL(k_attn_fwd<64>, grid, blk, 0, st, a);
   else hipLaunchKernelGGL(k_attn_fwd<32>, grid, blk, 0, st, a);
-  if (a.nsplit > 1) {
-    const int64_t rows = (int64_t)B * S, n = rows * (C / 8);
-    hipLaunchKernelGGL(k_attn_merge_fwd, dim3((unsigned)((n + 255) / 256)), blk, 0, st, a.part, a.part_ml, a.resid, a.y, lse, C, heads, S, rows,
-                       a.nsplit);
-  }
+  if (a.nsplit > 1) attn_merge_fwd_launch(a, B, st);
   MI_CHECK_LAUNCH();
   return 0;
 }
@@ -544,16 +509,16 @@ int mi_attn_fwd(const void* qkv, int ld, int C, int heads, int B, int S, float s
 // (O = y - resid is what the row term needs); dqkv receives dQ | dK | dV in the layout of qkv.  dsum: [B*heads][S] scratch.
 int mi_attn_bwd(const void* qkv, int ld, int C, int heads, int B, int S, float scale, const void* y, const void* resid, const void* dy,
                 const float* lse, float* dsum, void* dqkv, void* ws, int64_t ws_bytes, hipStream_t st) {
-  if (bad(C, heads, S, B, ld) || !qkv || !y || !dy || !lse || !dsum || !dqkv) return MI_ERR_BAD_ARG;
+  if (!qkv || !y || !dy || !lse || !dsum || !dqkv) return MI_ERR_BAD_ARG;
   AttnArgs a{};
   a.qkv = (const bf16*)qkv; a.ld = ld; a.C = C; a.heads = heads; a.S = S; a.scale = scale;
   a.dy = (const bf16*)dy; a.lse = const_cast<float*>(lse); a.dsum = dsum; a.dqkv = (bf16*)dqkv;
+  if (attnw_supported(C, heads)) return attnw_bwd(a, B, (const bf16*)y, (const bf16*)resid, ws, ws_bytes, st);
+  if (bad(C, heads, S, B, ld)) return MI_ERR_BAD_ARG;
   pick_split(B, heads, S, a.nsplit, a.tps);
   if (!ws || (size_t)ws_bytes < bwd_ws(C, B, S, a.nsplit)) a.nsplit = 1, a.tps = (S + 63) / 64;
   a.part = (bf16*)ws;
-  const int64_t rows = (int64_t)B * S;
-  hipLaunchKernelGGL(k_attn_dsum, dim3((int)((rows + 3) / 4)), dim3(256), 0, st, (const bf16*)dy, (const bf16*)y, (const bf16*)resid, dsum, C,
-                     heads, S, rows);
+  attn_dsum_launch(a, (const bf16*)y, (const bf16*)resid, B, st);
   dim3 grid((S + 127) / 128, B * heads, a.nsplit), blk(256);
   if (C / heads == 64) {
     hipLaunchKernelGGL(k_attn_bwd_dq<64>, grid, blk, 0, st, a);
@@ -562,10 +527,7 @@ int mi_attn_bwd(const void* qkv, int ld, int C, int heads, int B, int S, float s
     hipLaunchKernelGGL(k_attn_bwd_dq<32>, grid, blk, 0, st, a);
     hipLaunchKernelGGL(k_attn_bwd_dkv<32>, grid, blk, 0, st, a);
   }
-  if (a.nsplit > 1) {
-    const int64_t n = rows * (3 * C / 8);
-    hipLaunchKernelGGL(k_attn_merge_bwd, dim3((unsigned)((n + 255) / 256)), blk, 0, st, a.part, a.dqkv, ld, 3 * C, rows, a.nsplit);
-  }
+  if (a.nsplit > 1) attn_merge_bwd_launch(a, B, st);
   MI_CHECK_LAUNCH();
   return 0;
 }

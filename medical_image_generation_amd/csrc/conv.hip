@@ -2055,6 +2055,11 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   // odd multiple of 32 pads its last workgroup row with 32 dead channels: for 96 that is a third more MFMAs than needed (the data
   // gradient of the 96 -> 32 conv of the finest up-block: 434 us as 64 + 32(+32 dead), ~345 as 3 x 32)
   P->ncb_fwd = Cout > 32 && Cout != 96 ? 2 : 1;
+  {  // only the 32-channel variant carries the GroupNorm sums in its epilogue (above): up to this many output channels the forward runs
+     // as rows of 32 so that the consumer's statistics pass disappears (A/B knob; 32 = the plain rule)
+    static const int ncb1_max = env_int("MI_NCB1_FWD_MAXC", 32);
+    if (Cout <= ncb1_max && (Cout % 32) == 0) P->ncb_fwd = 1;
+  }
   P->ncb_dg = Cin > 32 && Cin != 96 ? 2 : 1;
   {  // few tiles (16^3 levels): 64 output channels per workgroup would leave most CUs without a workgroup -> 32 per workgroup
     const int64_t tiles = (int64_t)N * ((od[0] + 3) / 4) * ((od[1] + 7) / 8) * ((od[2] + 7) / 8);

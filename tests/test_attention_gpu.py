@@ -9,7 +9,13 @@ pytestmark = pytest.mark.gpu
 dev = torch.device("cuda")
 
 
-@pytest.mark.parametrize("B,H,S,d", [(1, 1, 64, 32), (2, 2, 64, 32), (1, 4, 512, 64), (2, 1, 1000, 64), (1, 2, 4096, 64), (1, 3, 200, 32)])
+# One wide head (csrc/attention_wide.hip): the reference's latent UNets (configuration.py:894, num_head_channels = [0, 512, 768]) at
+# the token counts of 8^3 .. 20^3 latents, a ragged count (1000, 125, 27), two images, and 8 tokens (fewer than one tile)
+WIDE = [(1, 1, 512, 512), (2, 1, 1000, 512), (1, 1, 4096, 512), (1, 1, 8000, 512), (1, 1, 125, 512), (1, 1, 1000, 768), (2, 1, 27, 768),
+        (1, 1, 8, 768)]
+
+
+@pytest.mark.parametrize("B,H,S,d", [(1, 1, 64, 32), (2, 2, 64, 32), (1, 4, 512, 64), (2, 1, 1000, 64), (1, 2, 4096, 64), (1, 3, 200, 32)] + WIDE)
 @pytest.mark.parametrize("split", [True, False])
 def test_flash_attention_fwd_bwd(B, H, S, d, split):
     """split: hand the kernels their scratch, so the reduction axis is cut into up to 8 partial passes + a merge kernel
@@ -33,6 +39,7 @@ def test_flash_attention_fwd_bwd(B, H, S, d, split):
     y = torch.empty_like(xd)
     lse = torch.empty(B * H, S, device=dev)
     nws = call_raw("mi_attn_workspace_bytes", C, H, B, S) if split else 0
+    assert call_raw("mi_attn_supported", C, H) == 1
     assert nws > 0 or not split or S < 512
     ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
     call("mi_attn_fwd", ptr(qd), 3 * C, C, H, B, S, scale, ptr(xd), ptr(y), ptr(lse), ptr(ws) if split else None, nws)
