@@ -827,8 +827,9 @@ struct DmaPieces {
 
 // x halo image: piece i (1 KiB) -> halo voxels 16 i .. 16 i + 15, lane -> voxel 16 i + (lane >> 2), 16-byte part lane & 3
 template <int MAXP>
-__device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane, int Hi, int Wi, int cs, int sx = 1) {
-  const int hvox = g.HD * g.HH * g.HW;
+__device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, int first, int stride, int npieces, int lane, int Hi, int Wi, int cs, int sx = 1,
+                                           int slices = 0) {  // slices: depth of the image when it is not the tile's whole halo (k_conv_wgrad3's groups)
+  const int hvox = (slices ? slices : g.HD) * g.HH * g.HW;
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
     const int i = first + stride * k;
@@ -841,13 +842,13 @@ __device__ __forceinline__ void dma_init_x(DmaPieces<MAXP>& d, const Geom& g, in
 // sx, cls: image voxel u = tensor voxel sx * u + (cls bit 2 / 1 / 0 along d / h / w) (WgradArgs::sx)
 template <int MAXP>
 __device__ __forceinline__ void dma_issue_x(const DmaPieces<MAXP>& d, const ConvArgs& a, char* dst, int first, int stride, int npieces, int lane,
-                                            int n, int d0, int h0, int w0, int src_c0, bool valid = true, int sx = 1, int cls = 0) {
+                                            int n, int d0, int h0, int w0, int src_c0, bool valid = true, int sx = 1, int cls = 0, int slices = 0) {
   const Geom& g = a.g;
   const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
   const int c = src_c0 + (lane & 3) * 8;
   const int od = sx * (d0 - g.hd) + ((cls >> 2) & 1), oh = sx * (h0 - g.hh) + ((cls >> 1) & 1), ow = sx * (w0 - g.hw) + (cls & 1);
   const unsigned base = (unsigned)((((n * a.Di + od) * a.Hi + oh) * a.Wi + ow) * a.x_cs + src_c0) * 2u;  // scalar (mod 2^32)
-  const bool interior = valid & (od >= 0) & (od + sx * (g.HD - 1) < a.Di) & (oh >= 0) & (oh + sx * (g.HH - 1) < a.Hi) & (ow >= 0) &
+  const bool interior = valid & (od >= 0) & (od + sx * ((slices ? slices : g.HD) - 1) < a.Di) & (oh >= 0) & (oh + sx * (g.HH - 1) < a.Hi) & (ow >= 0) &
                         (ow + sx * (g.HW - 1) < a.Wi) & (src_c0 + 32 <= a.Cin);
   if (interior) {
 #pragma unroll
@@ -1165,6 +1166,173 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad2(WgradArgs w) {
     __builtin_amdgcn_s_barrier();
     return;
   }
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    int ti = wave + 8 * t;
+    if (ti >= ntaps) continue;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int co = (e & 3) + 8 * (e >> 2) + 4 * h;
+      out[((int64_t)ti * 32 + co) * 32 + r] = acc[t][e];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient, rolling x halo
+// k3 s1 3-D layers.  k_conv_wgrad2's loader waves are its critical path (56 LDS-DMA pieces per tile at ~180 cycles each over four
+// waves = 2500 cycles against ~2200 for the 54 MFMAs of a compute wave), and 40 of the 56 are the x halo image -- a third of which
+// the PREVIOUS tile already had when a workgroup walks along D.  Here a workgroup owns a contiguous run of tiles in d-fastest order,
+// and the halo lives in a ring of three GROUPS of 4 d-slices (25,600 B = 25 whole pieces): the tile at depth d0 reads slices
+// d0-1 .. d0+4 = its first group and half of the second; the next tile along D reuses the second group as its first, so a step
+// fetches ONE group (25 pieces instead of 40).  The six slices must be contiguous for the compute waves' immediates: behind the
+// third group sits a copy of the first two slices of whatever group slot 0 holds (written with it: 13 more pieces every third
+// step), so a tile whose groups are slots (2, 0) reads straight on.  A tile that starts a column (or the run) needs two fresh
+// groups; the second one can only be requested once the previous tile has left its slot (exposed, once per column).
+constexpr int WR_GROUP = 4 * WG3_XSLICE;  // 25,600 B
+constexpr int WR_XRING = 88 * 1024;       // 3 groups + the 2-slice copy = 89,600 B, rounded up (the copy's 13th piece runs 512 B past it)
+constexpr int WR_YB = 16 * 1024;          // dY tile image (two of them)
+constexpr int WR_LDS = WR_XRING + 2 * WR_YB + 64;
+
+__global__ void __launch_bounds__(768, 3) k_conv_wgrad3(WgradArgs w) {
+  constexpr int MAXT = 4, MAXPG = 7, MAXPY = 4;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const ConvArgs& a = w.c;
+  const Geom& g = a.g;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned lds_base = (unsigned)(size_t)(lds_char*)lds;
+  unsigned* const fl_ready = (unsigned*)(lds + WR_XRING + 2 * WR_YB);  // tiles landed (x 4 loader waves); [1]: tiles left (x 8 compute waves)
+  unsigned* const fl_freed = fl_ready + 1;
+  if (threadIdx.x < 2) fl_ready[threadIdx.x] = 0u;  // (ordered before any use by the prologue barrier)
+  int pair, split;
+  if (w.nsplit >= 8) {  // XCD-aware placement: see k_conv_wgrad
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    pair = slot % w.npairs;
+    split = (slot / w.npairs) * 8 + xcd;
+  } else {
+    pair = blockIdx.x / w.nsplit;
+    split = blockIdx.x % w.nsplit;
+  }
+  if (split >= w.nsplit || pair >= w.npairs) return;  // whole workgroup, before any barrier
+  // run of tiles [t0, tend) in d-fastest order; the splits of one XCD class get neighbouring runs (their h / w halos meet in that L2)
+  const int run = (w.nsplit >= 8 && (w.nsplit & 7) == 0) ? (split & 7) * (w.nsplit >> 3) + (split >> 3) : split;
+  const int t0 = (int)((int64_t)run * w.ntiles / w.nsplit), tend = (int)((int64_t)(run + 1) * w.ntiles / w.nsplit);  // (nsplit <= ntiles: never empty)
+  const int y = pair / a.nchunks;
+  const int* hdr = a.hdr + (int64_t)pair * 4;
+  const int tap_begin = hdr[0], ntaps = hdr[1], src_c0 = hdr[2];
+  // digits of tile t0
+  int td = t0 % g.tilesD, tw = (t0 / g.tilesD) % g.tilesW, th = (t0 / (g.tilesD * g.tilesW)) % g.tilesH, n = t0 / (g.tilesD * g.tilesW * g.tilesH);
+  auto step_digits = [&]() -> bool {  // to the next tile of the run; true: it continues the column (the halo rolls)
+    if (++td < g.tilesD) return true;
+    td = 0;
+    if (++tw == g.tilesW) { tw = 0; if (++th == g.tilesH) { th = 0; ++n; } }
+    return false;
+  };
+
+  if (wave >= 8) {  // ---------------------------------------------------------------- loader waves
+    const int first = wave - 8;
+    DmaPieces<MAXPG> dg;
+    DmaPieces<MAXPY> dyp;
+    dma_init_x<MAXPG>(dg, g, first, 4, 25, lane, a.Hi, a.Wi, a.x_cs, 1, 4);
+    dma_init_y<MAXPY>(dyp, g, first, 4, 16, lane, a.Ho, a.Wo, w.dy_cs, 1);
+    auto group = [&](int slot, int dfirst) {  // slices dfirst .. dfirst+3 of the current (n, th, tw) column's halo -> group slot
+      dma_issue_x<MAXPG>(dg, a, lds + slot * WR_GROUP, first, 4, 25, lane, n, dfirst + g.hd, th * g.TH, tw * g.TW, src_c0, true, 1, 0, 4);
+      if (slot == 0) dma_issue_x<MAXPG>(dg, a, lds + 3 * WR_GROUP, first, 4, 13, lane, n, dfirst + g.hd, th * g.TH, tw * g.TW, src_c0, true, 1, 0, 4);
+    };
+    auto dytile = [&](int ybuf) {
+      dma_issue_y<MAXPY>(dyp, w, lds + WR_XRING + ybuf * WR_YB, first, 4, 16, lane, y, n, td * g.TD, th * g.TH, tw * g.TW, true, 1, 0);
+    };
+    int G = 0, it = 0;
+    group(0, td * g.TD - 1);
+    group(1, td * g.TD + 3);
+    dytile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // prologue
+    flag_bump(fl_ready, lane);
+    for (int t = t0 + 1; t < tend; ++t, ++it) {  // request tile t = number it+1 of the run while number it is being consumed
+      const bool rolls = step_digits();
+      if (it > 0) flag_wait(fl_freed, 8u * (unsigned)it);  // tiles 0 .. it-1 have been left: group slot (G + 2) % 3 and dY buffer (it + 1) & 1 are free
+      group((G + 2) % 3, rolls ? td * g.TD + 3 : td * g.TD - 1);
+      dytile((it + 1) & 1);
+      if (!rolls) {  // a new column: its second group goes where tile `it` still reads its first
+        flag_wait(fl_freed, 8u * (unsigned)(it + 1));
+        group(G % 3, td * g.TD + 3);
+      }
+      G += rolls ? 1 : 2;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      flag_bump(fl_ready, lane);
+    }
+    __builtin_amdgcn_s_barrier();  // every compute wave has finished its last tile
+    return;
+  }
+
+  // ------------------------------------------------------------------------------------ compute waves (as k_conv_wgrad2<true>)
+  const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+  const int kh = gq >> 1;
+  const int chan_b = ((gq & 1) * 16 + pp * 4) * 2;
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  int toff[MAXT];
+  int nt = 0;
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    int ti = wave + 8 * t;
+    toff[t] = a.taps[tap_begin + (ti < ntaps ? ti : 0)];
+    nt += ti < ntaps ? 1 : 0;
+  }
+  const bool do_colsum = w.colsum != nullptr && (pair % a.nchunks) < w.cs_chunks;
+  const int cs_slab = split * w.cs_chunks + (pair % a.nchunks);
+  const bool cs_wave = do_colsum && wave == 7;
+  f32x16& cs = acc[3];
+  auto cs_flush = [&](int img) {
+    if ((lane & 31) == 0) {
+      const int hh = lane >> 5;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = y * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (co < a.Cout) {
+          if (w.cs_part) w.cs_part[((int64_t)cs_slab * a.N + img) * a.Cout + co] = cs[e];
+          else atomicAdd(w.colsum + (int64_t)img * w.colsum_stride + co, cs[e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) cs[e] = 0.f;
+  };
+  int cs_n = n;
+  if (cs_wave && w.cs_part) {  // rows of images this workgroup never reaches must read as zero
+    for (int i = lane; i < a.N * 32; i += 64) {
+      const int img = i >> 5, co = y * 32 + (i & 31);
+      if (co < a.Cout) w.cs_part[((int64_t)cs_slab * a.N + img) * a.Cout + co] = 0.f;
+    }
+  }
+  __builtin_amdgcn_s_barrier();  // prologue: the first tile is in group slots 0, 1 and dY buffer 0
+  int G = 0, it = 0;
+  for (int t = t0; t < tend; ++t, ++it) {
+    flag_wait(fl_ready, 4u * (unsigned)(it + 1));
+    if (cs_wave && n != cs_n) {
+      cs_flush(cs_n);
+      cs_n = n;
+    }
+    const unsigned lds0 = lds_base + (G % 3) * WR_GROUP, ldy0 = lds_base + WR_XRING + (it & 1) * WR_YB;
+    {
+      f32x16(&a3)[3] = reinterpret_cast<f32x16(&)[3]>(acc);
+      const int(&t3)[3] = reinterpret_cast<const int(&)[3]>(toff);
+      if (nt == 4) wg3_tile<4, false>(acc, toff, cs, lds0, ldy0, kh, q, chan_b);
+      else if (cs_wave) wg3_tile<3, true>(a3, t3, cs, lds0, ldy0, kh, q, chan_b);
+      else wg3_tile<3, false>(a3, t3, cs, lds0, ldy0, kh, q, chan_b);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the tile have returned
+    flag_bump(fl_freed, lane);
+    if (t + 1 < tend) G += step_digits() ? 1 : 2;
+  }
+  __builtin_amdgcn_s_barrier();  // (pairs with the loaders')
+  if (cs_wave) cs_flush(cs_n);
+  float* out = w.part + (int64_t)split * w.split_stride + w.pair_off[pair];
+  const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int t = 0; t < MAXT; ++t) {
     int ti = wave + 8 * t;
@@ -2588,7 +2756,20 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
         if (e != hipSuccess) return (int)e;
         done = true;
       }
-      if (geo3) hipLaunchKernelGGL(k_conv_wgrad2<true>, grid, dim3(768), lds2, st, w);
+      static const int use_roll = env_int("MI_WGRAD_ROLL", 1);  // 0: k_conv_wgrad2 for every layer (A/B runs)
+      // (runs of more than two columns lose more to L2 locality -- the workgroups of an XCD are then columns apart -- than the saved
+      // pieces return: 64->64 and 96->32 at 128^3 measured +1 / +2.5 %, 32->32 -6 %, 64->32 -3.5 %, the 64^3 .. 16^3 levels -1.5 .. -3 %)
+      const bool roll = use_roll && geo3 && !direct && w.sx == 1 && w.sy == 1 && w.nbuf == 2 && w.flags && P->wg.hdr[1] == 27 && w.nsplit <= w.ntiles &&
+                        a.g.tilesD >= 2 && (use_roll > 1 || (int64_t)w.ntiles <= 2ll * a.g.tilesD * w.nsplit);
+      if (roll) {
+        static bool attr_r = false;
+        if (!attr_r) {
+          hipError_t e = hipFuncSetAttribute((const void*)k_conv_wgrad3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          if (e != hipSuccess) return (int)e;
+          attr_r = true;
+        }
+        hipLaunchKernelGGL(k_conv_wgrad3, grid, dim3(768), (size_t)WR_LDS, st, w);
+      } else if (geo3) hipLaunchKernelGGL(k_conv_wgrad2<true>, grid, dim3(768), lds2, st, w);
       else hipLaunchKernelGGL(k_conv_wgrad2<false>, grid, dim3(768), lds2, st, w);
 #ifdef MI_WG2_DIAG_BAR
       {
