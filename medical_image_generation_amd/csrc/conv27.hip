@@ -38,6 +38,32 @@ __global__ void __launch_bounds__(512, 2) k_conv27(ConvArgs a) {
   conv27_body<NCB, FLIP, 0>(a);
 }
 
+template <int FLIP>
+__global__ void __launch_bounds__(512, 2) k_conv27r(ConvArgs a) {
+  conv27r_body<FLIP>(a);
+}
+// single-chunk 32-channel layers with at least a few tiles per column: the rolling-halo variant (conv27_kernel.h, MODE 3)
+template <int FLIP>
+int launch27r(ConvArgs a, int ntiles, int ny, hipStream_t st) {
+  using KK = K<1, 3>;
+  a.ntiles = ntiles;
+  static const int dbg = mi_diag_knob("MI_C27_DBG");
+  a.dbg = dbg & ~64;
+  const int gx = mi_conv27_grid_x(ntiles, ny);
+  if (a.stats && a.stats_chunks != 4 * gx) return MI_ERR_BAD_ARG;
+  auto kern = k_conv27r<FLIP>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  static_assert(KK::LDS_TOTAL <= 160 * 1024, "LDS budget of the rolling variant");
+  hipLaunchKernelGGL(kern, dim3(gx, ny), dim3(512), (size_t)KK::LDS_TOTAL, st, a);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
 template <int NCB, int FLIP>
 int launch27(ConvArgs a, int ntiles, int ny, hipStream_t st) {
   using KK = K<NCB, 0>;
@@ -83,6 +109,9 @@ int mi_launch_conv27(const ConvArgs& a, int NCB, int flip, int ntiles, int ny, h
   if (a.g.TD != 4 || a.g.TH != 8 || a.g.TW != 8 || (a.x_cs & 7) || (a.Cin & 7)) return MI_ERR_BAD_ARG;
   if ((a.y_cs & 7) || (a.Cout & 7) || a.y_bytes == 0) return MI_ERR_UNSUPPORTED;  // whole 16-byte pieces only (the caller falls back)
   if (a.res && (a.res_bytes == 0 || (a.res_cs & 7))) return MI_ERR_UNSUPPORTED;  // (>= 4 GiB is not reachable with the x_bytes limit)
+  static const int use_roll = [] { const char* e = getenv("MI_C27_ROLL"); return e ? atoi(e) : 1; }();  // 0: the plain kernel (A/B runs)
+  if (NCB == 1 && a.nchunks == 1 && use_roll && a.g.tilesD >= 4 && a.Cin >= 32)
+    return flip ? launch27r<1>(a, ntiles, ny, st) : launch27r<0>(a, ntiles, ny, st);
   if (NCB == 1) return flip ? launch27<1, 1>(a, ntiles, ny, st) : launch27<1, 0>(a, ntiles, ny, st);
   if (NCB == 2) return flip ? launch27<2, 1>(a, ntiles, ny, st) : launch27<2, 0>(a, ntiles, ny, st);
   return MI_ERR_BAD_ARG;

@@ -30,6 +30,10 @@ template <> struct Cfg<1, 1> { static constexpr int GT = 4; };  // 2 groups of 4
 template <> struct Cfg<2, 1> { static constexpr int GT = 2; };  // 4 groups of 2 taps (8 KB)
 template <> struct Cfg<1, 2> { static constexpr int GT = 4; };
 template <> struct Cfg<2, 2> { static constexpr int GT = 2; };
+template <> struct Cfg<1, 3> { static constexpr int GT = 9; };  // MODE 3: MODE 0 with a rolling halo (single-chunk layers; end of this file)
+template <int MODE> constexpr bool kPhase = MODE == 1 || MODE == 2;
+constexpr int RGROUP = 4 * HSLICE;          // MODE 3: a group of 4 d-slices = 25 whole 1-KiB DMA pieces
+constexpr int RHALO = 3 * RGROUP + 13 * 1024;  // three groups + the copy of slot 0's first two slices (12.5 pieces, issued as 13)
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -56,14 +60,14 @@ __device__ unsigned long long g_c27_clk[16];  // diagnostic (MI_C27_DBG & 64): s
 
 template <int NCB, int MODE>
 struct K {
-  static constexpr int NT = MODE ? 8 : 27;  // taps per image
+  static constexpr int NT = kPhase<MODE> ? 8 : 27;  // taps per image
   static constexpr int GT = Cfg<NCB, MODE>::GT, NG = NT / GT;
   static_assert(NG * GT == NT && NG >= 2, "tap groups");
   static constexpr int FRAGS = GT * 2 * NCB, GROUP_BYTES = FRAGS * 1024, RING = RD * GROUP_BYTES;
   static constexpr int VOXP = NCB * 64;        // staging bytes per voxel (bf16), 16-byte slots XOR-swizzled with the voxel index
   static constexpr int PV = NCB * 4;           // 16-byte pieces per voxel
   static constexpr int STG_WAVE = 64 * VOXP;   // one compute wave's 64 voxels
-  static constexpr int RING0 = 2 * HALO_BYTES, STG0 = RING0 + RING, AV0 = STG0 + 4 * STG_WAVE;
+  static constexpr int RING0 = MODE == 3 ? RHALO : 2 * HALO_BYTES, STG0 = RING0 + RING, AV0 = STG0 + 4 * STG_WAVE;
   static constexpr int AV_WAVE = NCB * 2 * 64;  // per compute wave: bias (+ time embedding) of its accumulator channels [cb][h][16] fp32
   static constexpr int LDS_TOTAL = AV0 + 4 * AV_WAVE;
   static constexpr int PPT = (PV + NG - 2) / (NG - 1);  // store-epilogue pieces (of PV per helper wave and tile) processed per tap group
@@ -127,8 +131,8 @@ template <int Q, int T, int NCB, int FLIP, int MODE>
 __device__ __forceinline__ void issue_one(Frags<NCB>& f, const unsigned (&bb)[2][3][2], unsigned ab) {
   constexpr int U = FLIP ? 26 - T : T;
   // MODE 0: tap U of the 3x3x3 window; MODE 1 / 2: tap T = (td, th, tw) of the 2x2x2 box (the image's shift is in the lane bases)
-  constexpr int TH = MODE ? (T >> 1) & 1 : (U / 3) % 3;
-  constexpr int BOFF = MODE ? (T >> 2) * HSLICE + TH * HROW + (T & 1) * 64 : (U / 9) * HSLICE + TH * HROW + (U % 3) * 64;
+  constexpr int TH = kPhase<MODE> ? (T >> 1) & 1 : (U / 3) % 3;
+  constexpr int BOFF = kPhase<MODE> ? (T >> 2) * HSLICE + TH * HROW + (T & 1) * 64 : (U / 9) * HSLICE + TH * HROW + (U % 3) * 64;
   constexpr int t = T % Cfg<NCB, MODE>::GT;
   constexpr int HALF = 2 + NCB;  // reads per k-step
   constexpr int ks = Q / HALF, q = Q % HALF;
@@ -264,6 +268,7 @@ struct CState {
   unsigned abase, abase_next;  // A fragment-read bases: ring slot of the current / the next group
   int av_n;                    // image index the LDS bias table of this wave was loaded for
   int cur;                     // halo buffer of the current image
+  unsigned hdelta;             // MODE 0 / 3: byte step from the current image's halo to the next image's (set per image by the role)
   int slot;                    // ring slot of the previous group
   int resident;                // single chunk whose weight groups all fit the ring: loaded once, inner barriers skipped
   unsigned long long bw[4];    // MI_C27_DIAG_BAR
@@ -318,8 +323,8 @@ __device__ __forceinline__ void taps(CState<NCB>& s, int lane) {
       if constexpr (T < 8)
 #endif
       tap_body<T + 1, NCB, FLIP, MODE>(s.acc, s.fr[cur], s.fr[cur ^ 1], s.bcur, (T + 1) % KK::GT == 0 ? s.abase_next : s.abase);
-    } else if constexpr (MODE == 0) {  // next: first tap of the next image -- other halo buffer, next group's slot
-      const unsigned delta = s.cur ? 0u - (unsigned)HALO_BYTES : (unsigned)HALO_BYTES;
+    } else if constexpr (!kPhase<MODE>) {  // next: first tap of the next image -- other halo buffer (MODE 3: next ring position), next group's slot
+      const unsigned delta = s.hdelta;
 #pragma unroll
       for (int vb = 0; vb < 2; ++vb)
 #pragma unroll
@@ -424,6 +429,7 @@ __device__ __forceinline__ void compute_role(const ConvArgs& a, char* lds, int y
   while (true) {
     seq_next<MODE>(q, a, tile_step, tile_last);
     if constexpr (MODE != 0) phase_bases<NCB>(s.bnxt, wave, lane, q.nbuf, phase_shift<MODE>(q.npc));
+    else s.hdelta = s.cur ? 0u - (unsigned)HALO_BYTES : (unsigned)HALO_BYTES;
     if constexpr ((KK::NT & 1) != 0) {  // odd tap count: the two fragment sets swap roles from image to image
       if (par) taps<0, 1, NCB, FLIP, MODE>(s, lane);
       else taps<0, 0, NCB, FLIP, MODE>(s, lane);
@@ -478,7 +484,7 @@ __device__ __forceinline__ void issue_A(const ConvArgs& a, char* lds, int y, int
   // fragments are packed [cout group][chunk][tap][ks][cb] and every chunk of a k3 s1 conv has all 27 taps: no table lookup
   // (a load inside the loop would be a VECTOR load -- the kernel stores to global memory -- and drain the DMA queue);
   // MODE 1 / 2: [cout group][phase][chunk][tap of the box][ks][cb]
-  const int wfrag = MODE ? ((y * 8 + pc) * a.nchunks + ch) * (KK::NT * 2 * NCB) + j * KK::FRAGS : (y * a.nchunks + ch) * (27 * 2 * NCB) + j * KK::FRAGS;
+  const int wfrag = kPhase<MODE> ? ((y * 8 + pc) * a.nchunks + ch) * (KK::NT * 2 * NCB) + j * KK::FRAGS : (y * a.nchunks + ch) * (27 * 2 * NCB) + j * KK::FRAGS;
 #ifdef MI_C27_DIAG_W
   return;
 #endif
@@ -874,6 +880,215 @@ __device__ __forceinline__ void helper_role(const ConvArgs& a, char* lds, int y,
   }
   if (ST && a.stats && e.sn >= 0) stats_flush<NCB, MODE>(e, a, y, hl, lane);
   wait_vm<0>();
+}
+
+// ------------------------------------------------------------------------------------------------ MODE 3: rolling halo along D
+// Single-chunk 32-channel layers (weights resident).  A workgroup owns a contiguous run of tiles in d-fastest order and walks it column
+// segment by column segment.  Inside a segment the halo lives in a ring of three GROUPS of 4 d-slices: the tile at depth d0 reads
+// slices d0-1 .. d0+4 = its first group and half of its second; the next tile takes the second group as its first, so a step fetches
+// ONE group (25 pieces) instead of the whole halo image (38): the helper waves' LDS-DMA issue is what the compute waves wait for at
+// the barriers.  The six slices have to be contiguous for the fragment reads' immediates: behind the third group sits a
+// copy of the first two slices of whatever slot 0 holds (written together with it), so a tile on slots (2, 0) reads straight on.
+// A segment starts like the kernel does (both groups fetched, prologue barrier) and ends like it (final barrier, last tile stored).
+struct RSeg {
+  int t, tend;        // next tile of the run (d-fastest linear index), end of the run
+  int n, th, tw, td;  // digits of tile t
+};
+__device__ __forceinline__ void rseg_init(RSeg& r, const Geom& g, int t0, int tend) {
+  r.t = t0; r.tend = tend;
+  r.td = t0 % g.tilesD; t0 /= g.tilesD;
+  r.tw = t0 % g.tilesW; t0 /= g.tilesW;
+  r.th = t0 % g.tilesH;
+  r.n = t0 / g.tilesH;
+}
+__device__ __forceinline__ int rseg_len(const RSeg& r, const Geom& g) {  // tiles of the run left in the current column
+  const int a = r.tend - r.t, b = g.tilesD - r.td;
+  return a < b ? a : b;
+}
+__device__ __forceinline__ void rseg_advance(RSeg& r, const Geom& g, int len) {
+  r.t += len; r.td += len;
+  if (r.td >= g.tilesD) {
+    r.td = 0;
+    if (++r.tw == g.tilesW) { r.tw = 0; if (++r.th == g.tilesH) { r.th = 0; ++r.n; } }
+  }
+}
+
+template <int FLIP>
+__device__ __forceinline__ void compute_role_r(const ConvArgs& a, char* lds, int y, int wave, int lane, int t0, int tend) {
+  using KK = K<1, 3>;
+  CState<1> s;
+  unsigned bl[2][3][2];
+  {
+    const int r = lane & 31, h = lane >> 5, row = r >> 3, col = r & 7;
+#pragma unroll
+    for (int vb = 0; vb < 2; ++vb)
+#pragma unroll
+      for (int th = 0; th < 3; ++th)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bl[vb][th][ks] = wave * HSLICE + (vb * 4 + row) * HROW + col * 64 + (((ks * 2 + h) ^ ((row + th) & 3)) * 16);
+  }
+  RSeg rs;
+  rseg_init(rs, a.g, t0, tend);
+  load_av<1, 3>(s, a, lds, y, wave, lane, rs.n);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  init_acc<1, 3>(s, lds, wave, lane);
+  s.cur = 0; s.hdelta = 0u;
+  s.bw[0] = s.bw[1] = s.bw[2] = s.bw[3] = 0;
+  s.resident = 1;
+  int par = 0;
+  while (rs.t < rs.tend) {
+    const int nseg = rseg_len(rs, a.g);
+    if (rs.n != s.av_n) {  // image index changed (segment starts only: nothing of this wave's is in flight)
+      load_av<1, 3>(s, a, lds, y, wave, lane, rs.n);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      init_acc<1, 3>(s, lds, wave, lane);
+    }
+#pragma unroll
+    for (int vb = 0; vb < 2; ++vb)
+#pragma unroll
+      for (int th = 0; th < 3; ++th)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) s.bcur[vb][th][ks] = bl[vb][th][ks];  // the segment's first tile sits on group slots (0, 1)
+    s.slot = RD - 1;
+    s.abase = s.abase_next = KK::RING0 + lane * 16;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    C27_BARRIER();  // prologue of the segment: its first two groups (and, the first time, the weights) are in LDS
+    if (par) { issue_frags<0, 1, FLIP, 3>(s.fr[1], s.bcur, s.abase); wait_frags<1>(s.fr[1]); }
+    else { issue_frags<0, 1, FLIP, 3>(s.fr[0], s.bcur, s.abase); wait_frags<1>(s.fr[0]); }
+    for (int u = 0; u < nseg; ++u) {
+      const int c0 = u % 3, c1 = c0 == 2 ? 0 : c0 + 1;
+      s.hdelta = (unsigned)((c1 - c0) * RGROUP);  // (past the segment's last tile: fragments that nobody consumes, inside the ring)
+      if (par) taps<0, 1, 1, FLIP, 3>(s, lane);
+      else taps<0, 0, 1, FLIP, 3>(s, lane);
+      par ^= 1;
+      C27_BARRIER_T(s.bw[1]);  // the helper waves have read the previous tile out of the staging tile
+      if (!(a.dbg & 1)) stage_acc<1, 3>(s, lds, wave, lane);
+      init_acc<1, 3>(s, lds, wave, lane);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    C27_BARRIER();  // final of the segment: its last tile's staging is complete
+    rseg_advance(rs, a.g, nseg);
+  }
+}
+
+template <bool ST>
+__device__ __forceinline__ void helper_role_r(const ConvArgs& a, char* lds, int y, int hl, int lane, int t0, int tend) {
+  using KK = K<1, 3>;
+  constexpr int GPW = 7;  // group pieces per helper wave: pieces hl, hl + 4, ... < 25
+  int hp[GPW];
+  unsigned hoff[GPW];
+#pragma unroll
+  for (int k = 0; k < GPW; ++k) {
+    const int v = (hl + 4 * k) * 16 + (lane >> 2), p = lane & 3;  // < 400 for every piece < 25
+    const int hd = v / 100, rem = v - hd * 100, hh = rem / 10, hw = rem - hh * 10;
+    hp[k] = ((p ^ (hh & 3)) << 24) | (hd << 16) | (hh << 8) | hw;
+    hoff[k] = (unsigned)(((hd * a.Hi + hh) * a.Wi + hw) * a.x_cs + (p ^ (hh & 3)) * 8) * 2u;
+  }
+  const __amdgpu_buffer_rsrc_t rx = make_rsrc(a.x, a.x_bytes);
+  // slices dfirst .. dfirst+3 of column (n, h0, w0) -> group slot; slot 0 also feeds the copy behind the third group
+  auto group = [&](int slot, int n, int dfirst, int h0, int w0) {
+#ifdef MI_C27_DIAG_HALO
+    return;
+#endif
+    const int oh = h0 - 1, ow = w0 - 1;
+    const unsigned base = (unsigned)((((n * a.Di + dfirst) * a.Hi + oh) * a.Wi + ow) * a.x_cs) * 2u;
+    const bool interior = (dfirst >= 0) & (dfirst + 3 < a.Di) & (oh >= 0) & (oh + 9 < a.Hi) & (ow >= 0) & (ow + 9 < a.Wi) & (32 <= a.Cin);
+#pragma unroll
+    for (int k = 0; k < GPW; ++k) {
+      const int i = hl + 4 * k;
+      if (i >= 25) break;  // wave-uniform
+      unsigned off = hoff[k] + base;
+      if (!interior) {
+        const int pk = hp[k];
+        const int gd = dfirst + ((pk >> 16) & 255), gh = oh + ((pk >> 8) & 255), gw = ow + (pk & 255);
+        const bool ok = ((unsigned)gd < (unsigned)a.Di) & ((unsigned)gh < (unsigned)a.Hi) & ((unsigned)gw < (unsigned)a.Wi) & (((pk >> 24) & 3) * 8 + 8 <= a.Cin);
+        off = ok ? off : 0xfffffff0u;  // out of range -> zeros
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(lds + slot * RGROUP + i * 1024), 16, off, 0, 0, 0);
+      if (slot == 0 && i < 13) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_void*)(lds + 3 * RGROUP + i * 1024), 16, off, 0, 0, 0);
+    }
+  };
+  const bool has_res = a.res != nullptr;
+  Epi<1, 3> e;
+  e.active = 0; e.full = 0; e.n = e.d0 = e.h0 = e.w0 = 0; e.pc = 0;
+  e.ybase = e.rbase = 0;
+  {
+    const int vl = lane / KK::PV, sidx = lane % KK::PV, row = vl >> 3, col = vl & 7;
+    e.ylane = (unsigned)(((hl * a.Ho + row) * a.Wo + col) * a.y_cs + sidx * 8) * 2u;
+    e.rlane = (unsigned)(((hl * a.Ho + row) * a.Wo + col) * a.res_cs + sidx * 8) * 2u;
+    e.slane = (unsigned)(vl * KK::VOXP + ((sidx ^ (vl & (KK::PV - 1))) * 16));
+    e.yps = (unsigned)((8 / KK::PV) * a.Wo * a.y_cs) * 2u;
+    e.rps = (unsigned)((8 / KK::PV) * a.Wo * a.res_cs) * 2u;
+  }
+#pragma unroll
+  for (int p = 0; p < KK::PV; ++p) e.res[p] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) e.sa[j] = e.sq[j] = 0.f;
+  e.sn = -1;
+  if (ST && a.stats) stats_zero<1, 3>(a, y, hl, lane);
+  RSeg rs;
+  rseg_init(rs, a.g, t0, tend);
+  bool first = true;
+  while (rs.t < rs.tend) {
+    const int nseg = rseg_len(rs, a.g);
+    const int n = rs.n, h0 = rs.th * 8, w0 = rs.tw * 8;
+    group(0, n, rs.td * 4 - 1, h0, w0);
+    group(1, n, rs.td * 4 + 3, h0, w0);
+    if (first) {  // the weights: every tap group of the only chunk, once
+#pragma unroll
+      for (int j = 0; j < KK::NG; ++j) issue_A<1, 3>(a, lds, y, hl, lane, 0, 0, j, j);
+      first = false;
+    }
+    wait_vm<0>();
+    C27_BARRIER();  // prologue of the segment
+    for (int u = 0; u < nseg; ++u) {
+      const int d0 = (rs.td + u) * 4;
+      const bool epi = e.active != 0;
+      C27_BARRIER();
+      if (epi) stats_begin_tile<1, 3, ST>(e, a, y, hl, lane);
+      epi_issue_res<1, 3>(e, a, y, hl, lane, epi && has_res);
+      if (u + 1 < nseg) group((u + 2) % 3, n, d0 + 7, h0, w0);  // the next tile's second group: slices (d0 + 4) + 3 ..
+      wait_vm<0>();
+      C27_BARRIER();
+      if (epi) {
+        epi_process<0, KK::PV, 1, 3, ST>(e, a, lds, y, hl, lane, has_res);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // staging reads done
+        e.active = 0;
+      }
+      C27_BARRIER();
+      if (!(a.dbg & 1)) epi_begin_tile<1, 3>(e, a, y, n, d0, h0, w0, 0);
+    }
+    wait_vm<0>();
+    C27_BARRIER();  // final of the segment
+    if (e.active) {  // its last tile (the compute waves are at the next segment's prologue barrier, or done)
+      stats_begin_tile<1, 3, ST>(e, a, y, hl, lane);
+      epi_issue_res<1, 3>(e, a, y, hl, lane, has_res);
+      wait_vm<0>();
+      epi_process<0, KK::PV, 1, 3, ST>(e, a, lds, y, hl, lane, has_res);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      e.active = 0;
+    }
+    rseg_advance(rs, a.g, nseg);
+  }
+  if (ST && a.stats && e.sn >= 0) stats_flush<1, 3>(e, a, y, hl, lane);
+  wait_vm<0>();
+}
+
+template <int FLIP>
+__device__ __forceinline__ void conv27r_body(const ConvArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int y = blockIdx.y;
+  // run of this workgroup: the workgroups of one XCD class (blockIdx.x % 8) get neighbouring runs
+  const int nwg = gridDim.x, run = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int t0 = (int)((int64_t)run * a.ntiles / nwg), tend = (int)((int64_t)(run + 1) * a.ntiles / nwg);
+  if (t0 >= tend) {  // whole workgroup, before any barrier
+    if (FLIP == 0 && a.stats && wave >= 4) stats_zero<1, 3>(a, y, wave - 4, lane);
+    return;
+  }
+  if (wave < 4) compute_role_r<FLIP>(a, lds, y, wave, lane, t0, tend);
+  else helper_role_r<FLIP == 0>(a, lds, y, wave - 4, lane, t0, tend);
 }
 
 template <int NCB, int FLIP, int MODE>
