@@ -63,7 +63,8 @@ def pmc_traffic(kind, size):
 
 def kernel_roofline(kind, size, iters=20):
     """One conv kernel on its most frequent shape in the step (k3 s1 32->32 at full resolution: 7 launches each of forward,
-    dgrad and wgrad per step; the weight-gradient kernel k_conv_wgrad2 is the largest single kernel of the step by total time).
+    dgrad and wgrad per step; the weight-gradient kernels are the largest kernel family of the step by total time).  At this shape the
+    library runs the rolling-halo variants: k_conv27r<0> (forward) and k_conv_wgrad3 (weight gradient).
     HIP-event timing on the launch stream; algorithmic flops = 2 * voxels * 32 * 32 * 27."""
     from medical_image_generation_amd import hipops as ops
     dev = torch.device("cuda")
@@ -85,7 +86,7 @@ def kernel_roofline(kind, size, iters=20):
     e1.synchronize()
     sec = e0.elapsed_time(e1) / 1e3 / iters
     flops = 2.0 * size ** 3 * 32 * 32 * 27
-    name = {"fwd": "k_conv27<1,0>", "wgrad": "k_conv_wgrad2<true> (+ k_wgrad_reduce, ~5 us, inside the timed launch pair)"}[kind]
+    name = {"fwd": "k_conv27r<0>", "wgrad": "k_conv_wgrad3 (+ k_wgrad_reduce, ~5 us, inside the timed launch pair)"}[kind]
     return {"bound": "mfma", "achieved": flops / sec / 1e12, "peak": MFMA_PEAK_BF16 / 1e12, "unit": "TFLOP/s",
             "frac": flops / sec / MFMA_PEAK_BF16, "traffic": pmc_traffic(kind, size),
             "kernel": f"{name}: k3 s1 32->32 @{size}^3", "avg_launch_us": sec * 1e6,

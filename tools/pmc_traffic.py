@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-KERNEL = {"fwd": "k_conv27", "wgrad": "k_conv_wgrad2"}
+KERNEL = {"fwd": "k_conv27", "wgrad": "k_conv_wgrad"}  # substrings: k_conv27r<0> / k_conv27<..>, k_conv_wgrad3 / k_conv_wgrad2<..>
 
 
 def main():
