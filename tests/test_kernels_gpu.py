@@ -261,7 +261,9 @@ def wide_view(t):
 
 
 @pytest.mark.parametrize("n,cin,cout,dims,groups", [(2, 32, 32, (8, 8, 8), 32), (1, 64, 96, (5, 9, 11), 32), (1, 32, 64, (8, 16, 16), 16),
-                                                    (3, 16, 48, (4, 6, 6), 8)])
+                                                    (3, 16, 48, (4, 6, 6), 8),
+                                                    # >= 4 tiles along D: the rolling-halo variant (column segments, runs that end inside a column)
+                                                    (1, 32, 32, (16, 16, 16), 32), (2, 32, 32, (22, 16, 24), 32), (3, 32, 32, (32, 8, 8), 8)])
 def test_conv_emits_groupnorm_sums(ops, n, cin, cout, dims, groups):
     """The k3 s1 p1 forward kernel also emits per-channel sums of its (bf16) output; GroupNorm statistics built from them -- alone
     and as the first / second half of a channel concatenation -- must equal the statistics pass over the stored tensor."""
@@ -295,8 +297,10 @@ def test_conv_emits_groupnorm_sums(ops, n, cin, cout, dims, groups):
 def test_conv_residual_at_size(ops, c):
     """The residual pieces of the k3 s1 p1 kernel are loaded asynchronously a tap group ahead of their use; a load that is consumed
     (or whose register is copied) before it has landed only shows at sizes where HBM latency is real -- 8^3 cases pass by luck.
-    2 x 64^3: 2048 tiles, both register-blocking variants (c = 32: one 32-channel block per wave, c = 64: two).  The epilogue adds
-    the residual to the bf16-rounded accumulator, so the result is bit-exact against conv-without-residual + residual."""
+    2 x 64^3: 2048 tiles, both register-blocking variants (c = 32: one 32-channel block per wave -- the rolling-halo kernel --, c = 64:
+    two).  The epilogue adds the residual to the bf16-rounded accumulator, so the result is bit-exact against conv-without-residual +
+    residual.  (Adding it in fp32 inside the accumulator init of the 32-channel kernel was built and measured: 174 -> 145 us stand-alone,
+    nothing in the step -- there the launch is HBM-bound on x + residual + y -- and one rounding instead of the reference's two; dropped.)"""
     n, d = 2, 64
     g = torch.Generator().manual_seed(c)
     x = torch.randn(n, d, d, d, c, generator=g).to(dev, torch.bfloat16)

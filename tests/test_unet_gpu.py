@@ -118,7 +118,13 @@ def test_batch_consistency_at_realistic_size():
         y1 = net(x1, t1)
         y2 = net(x2, t2)
     assert torch.isfinite(y2).all()
-    assert torch.equal(y2[0:1], y1) and torch.equal(y2[1:2], y1)
+    # (Bit-identity across batch sizes is a canary, not a structural guarantee: the conv epilogue's fp32 GroupNorm partial sums cover a
+    # workgroup's run of tiles, which depends on the batch size.  It holds for the shipped kernels; a variant that added the residual
+    # before the conv's rounding moved the sums enough to flip roundings, and this random-weight net amplifies single flips to 1-2e-2
+    # (tools/diag/t_net_sens.py: statistics from the epilogue vs from the separate pass alone move the prediction by 1.3e-2).  If this
+    # fails after a kernel change: MI_FUSE_GN_STATS=0 must make it pass again, and y2[0] == y2[1] must still hold.)
+    assert torch.equal(y2[0:1], y2[1:2])
+    assert torch.equal(y2[0:1], y1)
     tr = DDPMTrainer(net, lr=1e-4)
     tr.forward_backward(x1, n1, t1)
     l1, g1 = float(tr.loss), tr.arena.grad[:tr.arena.n_trainable].clone()
