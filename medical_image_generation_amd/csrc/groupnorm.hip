@@ -279,29 +279,64 @@ __global__ void __launch_bounds__(256) k_gn_bwd_finalize(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
                                                          float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   extern __shared__ float sm[];  // [cpg][2] channel sums
-  __shared__ double red[8];
+  __shared__ double pd[512];     // [thread][2], then [channel][8][2]
+  __shared__ double tot[2];
   const int n = blockIdx.x / G, g = blockIdx.x % G;
   const int cpg = C / G;
   const float mean = mean_rstd[((int64_t)n * G + g) * 2], rstd = mean_rstd[((int64_t)n * G + g) * 2 + 1];
+  // All channels of the group at once (was: one block-wide fp64 reduction, two barriers, per channel in turn -- 8 serial rounds for
+  // the 256-channel levels, ~9 us per launch, 51 launches per C4 step): `per` threads per channel read its chunks (consecutive threads,
+  // consecutive float2), 8 threads per channel fold the strips, one thread per channel finishes.  cpg <= 32 (C <= 1024 at 32 groups);
+  // wider groups take several rounds of 32 channels.
   double m1 = 0.0, m2 = 0.0;
-  for (int i = 0; i < cpg; ++i) {  // channels of the group in turn; the 256 threads split the chunks
-    int c = g * cpg + i;
+  for (int i0 = 0; i0 < cpg; i0 += 32) {
+    const int nc = cpg - i0 < 32 ? cpg - i0 : 32, per = 256 / nc;  // per >= 8
+    const int i = threadIdx.x / per, j = threadIdx.x - i * per;
     double s1 = 0.0, s2 = 0.0;
-    const float2* p = (const float2*)(partial + ((int64_t)n * C + c) * chunks * 2);
-    for (int ch = threadIdx.x; ch < chunks; ch += 256) {
-      const float2 v = p[ch];
-      s1 += (double)v.x;
-      s2 += (double)v.y;
+    if (i < nc) {
+      const float2* p = (const float2*)(partial + ((int64_t)n * C + g * cpg + i0 + i) * chunks * 2);
+      for (int ch = j; ch < chunks; ch += per) {
+        const float2 v = p[ch];
+        s1 += (double)v.x;
+        s2 += (double)v.y;
+      }
     }
-    block_sum2_d(s1, s2, red);
-    double s2hat = (double)rstd * (s2 - (double)mean * s1);  // sum du * xhat
+    __syncthreads();  // (pd / sm of the previous round have been read)
+    pd[2 * threadIdx.x] = s1;
+    pd[2 * threadIdx.x + 1] = s2;
+    __syncthreads();
+    double f1 = 0.0, f2 = 0.0;
+    const int ci = threadIdx.x >> 3, k = threadIdx.x & 7;
+    if (ci < nc)
+      for (int jj = k; jj < per; jj += 8) {
+        f1 += pd[2 * (ci * per + jj)];
+        f2 += pd[2 * (ci * per + jj) + 1];
+      }
+    __syncthreads();
+    pd[2 * threadIdx.x] = f1;
+    pd[2 * threadIdx.x + 1] = f2;
+    __syncthreads();
+    if (threadIdx.x < nc) {
+      double t1 = 0.0, t2 = 0.0;
+      for (int k2 = 0; k2 < 8; ++k2) {
+        t1 += pd[2 * (threadIdx.x * 8 + k2)];
+        t2 += pd[2 * (threadIdx.x * 8 + k2) + 1];
+      }
+      const double s2hat = (double)rstd * (t2 - (double)mean * t1);  // sum du * xhat
+      sm[2 * (i0 + threadIdx.x)] = (float)t1;
+      sm[2 * (i0 + threadIdx.x) + 1] = (float)s2hat;
+      pd[2 * threadIdx.x] = (double)gamma[g * cpg + i0 + threadIdx.x] * t1;
+      pd[2 * threadIdx.x + 1] = (double)gamma[g * cpg + i0 + threadIdx.x] * s2hat;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
-      sm[2 * i] = (float)s1;
-      sm[2 * i + 1] = (float)s2hat;
+      double a1 = i0 ? tot[0] : 0.0, a2 = i0 ? tot[1] : 0.0;
+      for (int c2 = 0; c2 < nc; ++c2) { a1 += pd[2 * c2]; a2 += pd[2 * c2 + 1]; }
+      tot[0] = a1; tot[1] = a2;
     }
-    m1 += (double)gamma[c] * s1;  // identical in every lane after the butterfly
-    m2 += (double)gamma[c] * s2hat;
   }
+  __syncthreads();
+  m1 = tot[0]; m2 = tot[1];
   __syncthreads();
   const double m = (double)V * cpg;
   m1 /= m;
