@@ -105,9 +105,10 @@ int mi_conv_pack_batch_destroy(mi_pack_batch* batch);
  * addvec: fp32 [Cout] (addvec_stride 0: bias) or N rows of pitch addvec_stride (bias + time-embedding projection, UNet:692-695) */
 int mi_conv_fwd(mi_conv_plan* plan, const void* x, int x_cstride, const float* scale_shift, int silu, const float* addvec,
                 int addvec_stride, const void* res, int res_cstride, void* y, int y_cstride, float* out_stats, hipStream_t stream);
-/* out_stats (optional): the k3 s1 p1 3-D kernel also emits per-channel (sum, sum of squares) of its bf16 output, so the GroupNorm
- * that consumes y (UNet:628, 648) needs no statistics pass over it: fp32 [N][Cout][chunks][2] with chunks = mi_conv_fwd_stats_chunks
- * (0: this plan's forward cannot -- strided / 1x1 / 2-D convs and the 64-channels-per-workgroup variant -- pass NULL), every entry written.  Feed it to mi_gn_stats_from_partial. */
+/* out_stats (optional): the k3 s1 p1 3-D kernel (32-channel rows) and the 1 -> C kernel of a network's input conv (C <= 32, no residual)
+ * also emit per-channel (sum, sum of squares) of their bf16 output, so the GroupNorm that consumes y (UNet:628, 648) needs no statistics
+ * pass over it: fp32 [N][Cout][chunks][2] with chunks = mi_conv_fwd_stats_chunks (0: this plan's forward cannot -- strided / 1x1 / 2-D
+ * convs and the 64-channels-per-workgroup variant -- pass NULL), every entry written.  Feed it to mi_gn_stats_from_partial. */
 int mi_conv_fwd_stats_chunks(const mi_conv_plan* plan);
 /* dx = conv_transpose(dy)  (gradient w.r.t. the ACTIVATED input) */
 int mi_conv_dgrad(mi_conv_plan* plan, const void* dy, int dy_cstride, void* dx, int dx_cstride, hipStream_t stream);

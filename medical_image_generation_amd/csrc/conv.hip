@@ -2294,7 +2294,11 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
     int64_t best = -1;
     for (int ns = 1; ns <= 256 && ns <= ntiles; ++ns) {
       const int per_xcd = ns >= 8 ? npairs * ((ns + 7) / 8) : (npairs * ns + 7) / 8;  // (k_conv_wgrad[2]: XCD-aware placement from 8 splits on)
-      const int64_t rounds = (per_xcd + 31) / 32, cost = rounds * ((ntiles + ns - 1) / ns + 6);
+      // (+ optionally the slab round trip: every split writes its slab and the reduce kernel reads it back; MI_WGRAD_SLAB_COST =
+      // hundredths of a tile time per MB and split -- 2 x 1 MB / 3 TB/s = 0.67 us = ~22; measured: no setting moves the step, default 0)
+      static const int slab_cost = env_int("MI_WGRAD_SLAB_COST", 0);
+      const int64_t rounds = (per_xcd + 31) / 32;
+      const int64_t cost = 100 * rounds * ((ntiles + ns - 1) / ns + 6) + (int64_t)slab_cost * ns * (off * 4 / (1 << 20));
       if (best < 0 || cost < best) { best = cost; nsplit = ns; }
     }
   }
@@ -2514,6 +2518,7 @@ int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
 }
 
 int mi_conv_fwd_stats_chunks(const mi_conv_plan* P) {
+  if (P && !P->up && P->c1_in) return mi_c1_expand_stats_chunks(P->N, P->Di, P->Hi, P->Wi, P->Cout);  // the network's input conv (conv_c1.hip)
   if (!P || P->up || !P->v27_fwd || P->N > 16 || P->ncb_fwd != 1) return 0;
   return 4 * mi_conv27_grid_x(P->N * P->g_fwd.tilesD * P->g_fwd.tilesH * P->g_fwd.tilesW, P->fwd.ny);
 }
@@ -2521,7 +2526,7 @@ int mi_conv_fwd_stats_chunks(const mi_conv_plan* P) {
 int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shift, int silu, const float* addvec, int addvec_stride,
                 const void* res, int res_cs, void* y, int y_cs, float* out_stats, hipStream_t st) {
   if (!P || !x || !y || x_cs < P->Cin || y_cs < P->Cout) return MI_ERR_BAD_ARG;
-  if (out_stats && (!mi_conv_fwd_stats_chunks(P) || scale_shift || (x_cs & 7))) return MI_ERR_UNSUPPORTED;  // only the conv27 path emits them
+  if (out_stats && (!mi_conv_fwd_stats_chunks(P) || scale_shift || ((x_cs & 7) && !P->c1_in))) return MI_ERR_UNSUPPORTED;  // conv27 / 1 -> C paths only
   if (P->ph_fwd.mode && !scale_shift && !res) {  // Upsample + conv (scatter) / k3 s2 conv (gather) on the phase kernels
     const int e = phase_side_run(P->ph_fwd, x, x_cs, P->Di, P->Hi, P->Wi, y, y_cs, P->Do, P->Ho, P->Wo, P->N, addvec, addvec_stride, st);
     if (e != MI_ERR_UNSUPPORTED) return e;
@@ -2533,10 +2538,12 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
     return mi_conv_fwd(P->up_inner, P->d_xup, P->Cin, scale_shift, silu, addvec, addvec_stride, res, res_cs, y, y_cs, nullptr, st);
   }
   if ((P->c1_in || P->c1_out) && P->c1_packed && !scale_shift && !res) {
-    int e = P->c1_in ? mi_launch_c1_expand(x, x_cs, P->d_c1w, addvec, addvec_stride, y, y_cs, P->N, P->Di, P->Hi, P->Wi, P->Cout, 0, st)
+    if (out_stats && !P->c1_in) return MI_ERR_UNSUPPORTED;
+    int e = P->c1_in ? mi_launch_c1_expand(x, x_cs, P->d_c1w, addvec, addvec_stride, y, y_cs, P->N, P->Di, P->Hi, P->Wi, P->Cout, 0, st, out_stats)
                      : mi_launch_c1_reduce(x, x_cs, P->d_c1w, addvec, addvec_stride, y, y_cs, P->N, P->Di, P->Hi, P->Wi, P->Cin, st);
     if (e != MI_ERR_UNSUPPORTED) return e;
   }
+  if (out_stats && P->c1_in) return MI_ERR_UNSUPPORTED;  // (the table-driven fallback of a single-channel conv emits no sums: never silently)
   ConvArgs a;
   memset(&a, 0, sizeof(a));
   const bf16* src = (const bf16*)x;

@@ -28,6 +28,10 @@ struct C1Args {
   int av_stride;
   bf16* y;
   int y_cs;
+  // k_c1_expand_mfma<1, 0> only: per-channel (sum, sum of squares) of the bf16 OUTPUT in the layout of the GroupNorm partials,
+  // stats[n][c][chunk][2], chunk = blockIdx.x, stats_chunks = gridDim.x (every entry written); null: none
+  float* stats;
+  int stats_chunks;
 };
 
 // ---------------------------------------------------------------------------------------------- 1 -> C (and dgrad of C -> 1)
@@ -137,6 +141,41 @@ __global__ void __launch_bounds__(256) k_c1_expand_mfma(C1Args a, int ntiles) {
       sreg[i] = in ? sn[(((int64_t)zz * a.H + yy) * a.W + xx) * a.s_cs] : f2bf(0.f);
     }
   };
+  // GroupNorm sums of the rounded output (the network's input conv feeds the first norm1 and, as a skip, the last concatenation:
+  // 74 + 66 us of statistics passes per C4 step).  A lane's channels are fixed (16 h + e); per image: fold the 32 lanes of a half
+  // wave, the 4 waves through LDS, one entry per workgroup.
+  constexpr bool ST = NCB == 1 && FLIP == 0;
+  __shared__ float sred[4][2][32];
+  float sa[16], sq[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sa[e] = sq[e] = 0.f;
+  int sn = -1;
+  auto stats_flush = [&](int img) {  // workgroup-uniform call sites
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) {
+        sa[e] += __shfl_xor(sa[e], m, 64);
+        sq[e] += __shfl_xor(sq[e], m, 64);
+      }
+    }
+    __syncthreads();
+    if (v == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { sred[wave][0][16 * h + e] = sa[e]; sred[wave][1][16 * h + e] = sq[e]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 && (int)threadIdx.x < a.C) {
+      const int c = threadIdx.x;
+      const float s0 = (sred[0][0][c] + sred[1][0][c]) + (sred[2][0][c] + sred[3][0][c]);
+      const float s1 = (sred[0][1][c] + sred[1][1][c]) + (sred[2][1][c] + sred[3][1][c]);
+      *(float2*)(a.stats + (((int64_t)img * a.C + c) * a.stats_chunks + blockIdx.x) * 2) = make_float2(s0, s1);
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sa[e] = sq[e] = 0.f;
+  };
+  if (ST && a.stats && threadIdx.x < 32 && (int)threadIdx.x < a.C)  // (a workgroup may not see tiles of every image)
+    for (int img = 0; img < a.N; ++img) *(float2*)(a.stats + (((int64_t)img * a.C + threadIdx.x) * a.stats_chunks + blockIdx.x) * 2) = make_float2(0.f, 0.f);
   int tile = blockIdx.x, buf = 0;
   if (tile < ntiles) issue(tile);
   for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
@@ -151,6 +190,10 @@ __global__ void __launch_bounds__(256) k_c1_expand_mfma(C1Args a, int ntiles) {
     const int ty = r % th; r /= th;
     const int tz = r % td, n = r / td;
     const int z = tz * kTD + wave;
+    if (ST && a.stats && n != sn) {  // (the image index never decreases along a workgroup's walk)
+      if (sn >= 0) stats_flush(sn);
+      sn = n;
+    }
     if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {  // 32 voxels: rows 4 blk .. 4 blk + 3 of this wave's d-slice
@@ -181,12 +224,22 @@ __global__ void __launch_bounds__(256) k_c1_expand_mfma(C1Args a, int ntiles) {
           F8 lo, hi;
 #pragma unroll
           for (int e = 0; e < 8; ++e) { lo.v[e] = acc[cb][e]; hi.v[e] = acc[cb][8 + e]; }
-          if (c0 < a.C) *(u32x4*)(out + c0) = pack8(lo);
-          if (c0 + 8 < a.C) *(u32x4*)(out + c0 + 8) = pack8(hi);
+          const u32x4 plo = pack8(lo), phi = pack8(hi);
+          if (c0 < a.C) *(u32x4*)(out + c0) = plo;
+          if (c0 + 8 < a.C) *(u32x4*)(out + c0 + 8) = phi;
+          if (ST && a.stats) {  // statistics of the ROUNDED values: what the consumer's GroupNorm will read (channels >= C hold zeros)
+            const F8 rl = unpack8(plo), rh = unpack8(phi);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              sa[e] += rl.v[e]; sq[e] = fmaf(rl.v[e], rl.v[e], sq[e]);
+              sa[8 + e] += rh.v[e]; sq[8 + e] = fmaf(rh.v[e], rh.v[e], sq[8 + e]);
+            }
+          }
         }
       }
     }
   }
+  if (ST && a.stats && sn >= 0) stats_flush(sn);
 }
 
 // ---------------------------------------------------------------------------------------------- C -> 1 forward
@@ -413,13 +466,27 @@ bool c1_dims_ok(int N, int D, int H, int W, int C) {
 
 }  // namespace
 
+static int c1_use_mfma() {
+  static const int v = [] { const char* e = getenv("MI_C1_EXPAND_MFMA"); return e ? atoi(e) : 1; }();
+  return v;
+}
+// chunks of the statistics the 1 -> C forward emits (0: this shape does not emit them)
+int mi_c1_expand_stats_chunks(int N, int D, int H, int W, int C) {
+  static const int on = [] { const char* e = getenv("MI_C1_STATS"); return e ? atoi(e) : 1; }();  // 0: separate statistics pass (A/B runs)
+  if (!on || !c1_use_mfma() || !c1_dims_ok(N, D, H, W, C) || C > 32 || N > 16) return 0;
+  const int64_t tiles = (int64_t)N * ((D + kTD - 1) / kTD) * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
+  if (tiles >= (1ll << 31)) return 0;
+  return (int)(tiles < 2048 ? tiles : 2048);
+}
 int mi_launch_c1_expand(const void* s, int s_cs, const float* w, const float* addvec, int av_stride, void* y, int y_cs, int N, int D, int H,
-                        int W, int C, int flip, hipStream_t st) {
+                        int W, int C, int flip, hipStream_t st, float* stats) {
   if (!c1_dims_ok(N, D, H, W, C) || (y_cs & 7)) return MI_ERR_UNSUPPORTED;
   C1Args a{};
   a.N = N; a.D = D; a.H = H; a.W = W; a.C = C;
   a.s = (const bf16*)s; a.s_cs = s_cs; a.w = w; a.addvec = addvec; a.av_stride = av_stride; a.y = (bf16*)y; a.y_cs = y_cs;
-  static const int use_mfma = [] { const char* e = getenv("MI_C1_EXPAND_MFMA"); return e ? atoi(e) : 1; }();
+  a.stats = stats; a.stats_chunks = stats ? mi_c1_expand_stats_chunks(N, D, H, W, C) : 0;
+  if (stats && (flip || a.stats_chunks == 0)) return MI_ERR_UNSUPPORTED;
+  const int use_mfma = c1_use_mfma();
   const int64_t tiles = (int64_t)N * ((D + kTD - 1) / kTD) * ((H + kTH - 1) / kTH) * ((W + kTW - 1) / kTW);
   if (use_mfma && tiles < (1ll << 31)) {
     const int grid = (int)(tiles < 2048 ? tiles : 2048);  // persistent: 8 workgroups of 4 waves per CU

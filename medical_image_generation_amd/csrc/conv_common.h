@@ -139,7 +139,8 @@ int mi_launch_wgrad1x1(const void* x, int x_cs, int Cin, const void* dy, int dy_
                        int colsum_stride, hipStream_t st);
 // conv_c1.hip: k3 s1 p1 3-D convs with one channel on one side (fp32 master weights [C][27] read directly)
 int mi_launch_c1_expand(const void* s, int s_cs, const float* w, const float* addvec, int av_stride, void* y, int y_cs, int N, int D, int H,
-                        int W, int C, int flip, hipStream_t st);
+                        int W, int C, int flip, hipStream_t st, float* stats = nullptr);  // stats: GroupNorm sums of the output (forward, C <= 32)
+int mi_c1_expand_stats_chunks(int N, int D, int H, int W, int C);
 int mi_launch_c1_wgrad(const void* m, int m_cs, const void* s1, int s_cs, float* dw, float* colsum_m, float* colsum_s, float* part, int N, int D,
                        int H, int W, int C, int flip, hipStream_t st);
 int64_t mi_c1_wgrad_scratch_floats(int C);

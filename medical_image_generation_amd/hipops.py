@@ -250,7 +250,7 @@ class ConvPlan:
             assert addvec.shape == (n, self.cout) and addvec.stride(1) == 1
             av_stride = addvec.stride(0)
         sums = None
-        if want_sums and FUSE_GN_STATS and st is None and self.stats_chunks > 0 and _cs(x) % 8 == 0:
+        if want_sums and FUSE_GN_STATS and st is None and self.stats_chunks > 0 and (_cs(x) % 8 == 0 or (self.cin == 1 and res is None)):
             sums = ChannelSums(torch.empty((n, self.cout, self.stats_chunks, 2), dtype=F32, device=x.device), self.stats_chunks, self.cout)
         call("mi_conv_fwd", self.handle, ptr(x), _cs(x), ptr(st.scale_shift) if st is not None else None, int(silu), ptr(addvec), av_stride,
              ptr(res), _cs(res) if res is not None else 0, ptr(y), _cs(y), ptr(sums.partial) if sums is not None else None)

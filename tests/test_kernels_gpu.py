@@ -293,6 +293,25 @@ def test_conv_emits_groupnorm_sums(ops, n, cin, cout, dims, groups):
         check(got2.scale_shift.cpu(), ref2.scale_shift.cpu(), 1e-4, f"scale/shift from two sources, {g2} groups")
 
 
+@pytest.mark.parametrize("n,cout,dims,groups", [(2, 32, (8, 8, 8), 32), (1, 32, (20, 16, 24), 8), (3, 16, (5, 9, 11), 4), (1, 24, (64, 64, 64), 8)])
+def test_input_conv_emits_groupnorm_sums(ops, n, cout, dims, groups):
+    """The 1 -> C forward kernel of the network's input conv (conv_c1.hip) emits the same per-channel sums: statistics built from them
+    equal the statistics pass over the stored tensor, for several images, ragged tiles and more tiles than persistent workgroups."""
+    x, w = rnd(n, 1, *dims), rnd(cout, 1, 3, 3, 3, scale=1.0 / math.sqrt(27))
+    bias = rnd(cout, seed=3)
+    plan = ops.ConvPlan(n, dims, 1, cout, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    assert plan.stats_chunks > 0
+    plan.pack(w.to(dev))
+    y, sums = plan.fwd(cl(x), addvec=bias.to(dev), want_sums=True)
+    assert sums is not None and torch.equal(y, plan.fwd(cl(x), addvec=bias.to(dev)))
+    v = dims[0] * dims[1] * dims[2]
+    gamma, beta = (1 + 0.2 * rnd(cout, seed=5)).to(dev), (0.1 * rnd(cout, seed=6)).to(dev)
+    ref = ops.gn_stats(y, groups, 1e-6, gamma, beta)
+    got = ops.gn_stats_from_sums(sums, None, n, v, groups, 1e-6, gamma, beta)
+    check(got.scale_shift.cpu(), ref.scale_shift.cpu(), 1e-4, "scale/shift from the input conv's sums")
+    check(got.mean_rstd.cpu(), ref.mean_rstd.cpu(), 1e-4, "mean/rstd from the input conv's sums")
+
+
 @pytest.mark.parametrize("c", [32, 64])
 def test_conv_residual_at_size(ops, c):
     """The residual pieces of the k3 s1 p1 kernel are loaded asynchronously a tap group ahead of their use; a load that is consumed
