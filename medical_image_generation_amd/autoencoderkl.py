@@ -10,7 +10,8 @@ latent tensors.
 `use_checkpointing=True` checkpoints the whole encoder and the whole decoder, like the reference's torch.utils.checkpoint calls
 (AEKL:761-762, 815-816): their activations are dropped after the forward and recomputed inside the backward (engine.checkpoint;
 gradients bit-identical to the stored-activation path).
-`use_convtranspose=True` raises NotImplementedError (never set by the reference's planner, CFG:843).
+`use_convtranspose=True` (never set by the reference's planner, CFG:843) runs as the data gradient of the matching strided conv
+(engine.conv_transpose) for 3-D kernel-3 / padding-1 / stride-2 (or 1) levels and raises NotImplementedError otherwise.
 """
 from __future__ import annotations
 
@@ -56,8 +57,7 @@ class AutoencoderKL(HipModule):
                              "`num_channels`.")
         if use_flash_attention:
             raise ValueError("torch.cuda.is_available() should be True but is False. Flash attention is only available for GPU.")
-        if use_convtranspose:
-            raise NotImplementedError("use_convtranspose=True is not on the HIP path (never set by the reference, CFG:843)")
+        self.use_convtranspose = bool(use_convtranspose)
         if spatial_dims not in (2, 3):
             raise ValueError("spatial_dims must be 2 or 3")
 
@@ -132,7 +132,10 @@ class AutoencoderKL(HipModule):
                 in_c = out_c
                 if ratt[i]:
                     attn(Dp, "decoder", in_c)
-            if i != L - 1:  # Upsample: nearest x stride, then a FIXED k3/p1 conv (AEKL:78-86, 99-105)
+            if i != L - 1 and use_convtranspose:  # Upsample = ConvTranspose(stride, kernel, padding) (AEKL:66-77); weight [in, out, k..]
+                n = add(Dp, "decoder", "upT", _axis3(us[i][1], sd, 1), _axis3(us[i][0], sd, 1), _axis3(us[i][2], sd, 0))
+                spec.conv(n + ".conv.conv", in_c, in_c, us[i][1])
+            elif i != L - 1:  # Upsample: nearest x stride, then a FIXED k3/p1 conv (AEKL:78-86, 99-105)
                 n = add(Dp, "decoder", "up", tuple(int(v) for v in _axis3(us[i][0], sd, 1)))
                 spec.conv(n + ".conv.conv", in_c, in_c, 3)
         spec.norm(add(Dp, "decoder", "norm"), in_c)
@@ -179,6 +182,8 @@ class AutoencoderKL(HipModule):
                 pending_norm = E.gn(c, x, name, self.groups, self.eps)
             elif kind == "up":
                 x = E.upsample_conv(c, x, name + ".conv.conv", step[2], self._k3, self._p1)
+            elif kind == "upT":
+                x = E.conv_transpose(c, x, name + ".conv.conv", step[2], step[3], step[4])
             first = False
         return x
 

@@ -301,6 +301,49 @@ def upsample_conv(ctx: Ctx, x, name, factors, kernel, padding, out=None):
     return conv(ctx, x, name, kernel, (1, 1, 1), padding, out=out, upconv=True)
 
 
+def conv_transpose(ctx: Ctx, x, name, kernel, stride, padding):
+    """AE Upsample(use_convtranspose=True) (AEKL:66-77): monai's Convolution(is_transposed=True) = nn.ConvTranspose3d(kernel, stride,
+    padding, output_padding = stride - 1), weight `name.weight` [Cin, Cout, k, k, k].  A transposed convolution is the data gradient of
+    the convolution C: z -> u with the same weight tensor read as [Cout_C = Cin, Cin_C = Cout]: forward = C's dgrad (the phase kernels
+    of a k3 s2 p1 conv write the twice finer grid directly), input gradient = C's forward, weight gradient = C's wgrad with (dy, x) in
+    the roles of (input, output gradient).  The bias rides in one affine pass over the output.  Supported: 3-D, kernel 3, padding 1,
+    stride 2 (or 1) on all axes -- what per-level (stride, kernel, padding) triples of compute_downsample_parameters (CFG:751-797) give."""
+    n, d, h, w, cin = x.shape
+    wt = ctx.p(name + ".weight")  # [Cin, Cout, 3, 3, 3]
+    cout = wt.shape[1]
+    k, s_, p_ = tuple(kernel), tuple(stride), tuple(padding)
+    if d <= 1 or k != (3, 3, 3) or p_ != (1, 1, 1) or s_ not in ((1, 1, 1), (2, 2, 2)) or cin % 8 or cout % 8:
+        raise NotImplementedError(f"use_convtranspose: kernel {k} stride {s_} padding {p_} ({cin}->{cout}) is not on the HIP path "
+                                  "(3-D, kernel 3, padding 1, stride 1 or 2 on all axes, channels in multiples of 8)")
+    fine = tuple(v * s_[0] for v in (d, h, w))  # output_padding = stride - 1: exactly stride x the input extent
+    key = (name, n, d, h, w)
+    plan = ctx.plans.get(key)
+    if plan is None:
+        plan = ctx.plans[key] = ops.ConvPlan(n, fine, cout, cin, k, s_, p_)  # the convolution C on the fine grid: Cout -> Cin channels
+    if key not in ctx.packed:
+        plan.pack(wt)
+        ctx.packed.add(key)
+    y0 = plan.dgrad(x)
+    bias = ctx.p(name + ".bias")
+    ss = torch.stack([torch.ones_like(bias), bias], dim=1).unsqueeze(0).expand(n, cout, 2).contiguous()
+    y = ops.gn_apply(y0, ops.GNStats(ss, None, 1), False)  # y = 1 * y0 + bias
+    del y0
+    ctx.count(2 * y.numel() * cin * 27 // (s_[0] ** 3), dgrad=True)
+    if ctx.tape is not None:
+        tape = ctx.tape
+
+        def bwd():
+            dy = tape.take(y)
+            if dy is None:
+                return
+            plan.wgrad(dy, x, ctx.g(name + ".weight"))
+            ops.colsum(dy.contiguous(), out=ctx.g(name + ".bias"), accumulate=True, merge_batch=True)
+            tape.put(x, plan.fwd(dy))
+
+        tape.record(bwd)
+    return y
+
+
 def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addvec=None, res=None, d_addvec=None,
          need_dx=True, bias_grad_like=None, out=None, upconv=False):
     """y = conv(act(x)) + addvec + res   (weight `name.weight`, bias folded into addvec by the caller or taken from

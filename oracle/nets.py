@@ -423,8 +423,10 @@ class AutoencoderKL(nn.Module):
             raise ValueError("num_res_blocks must be an int or have the same length as num_channels")
         if use_flash_attention:
             raise ValueError("use_flash_attention needs xformers + CUDA; not available to the oracle")
-        if use_convtranspose:
-            raise NotImplementedError("use_convtranspose=True: monai ConvTranspose wrapper, parity unpinned")
+        # use_convtranspose=True (AEKL:66-77): Upsample = monai Convolution(is_transposed=True).  monai is not under /root/reference:
+        # restated from its published form -- nn.ConvTranspose{2,3}d(kernel, stride, padding, output_padding = stride - 1), weight
+        # [in, out, k..] -- PARITY UNPINNED.
+        self.use_convtranspose = bool(use_convtranspose)
 
         sd = self.sd = spatial_dims
         self.groups, self.eps = norm_num_groups, norm_eps
@@ -489,7 +491,10 @@ class AutoencoderKL(nn.Module):
                 in_c = out_c
                 if ratt[i]:
                     attn(D, "decoder", in_c)
-            if i != L - 1:
+            if i != L - 1 and use_convtranspose:
+                n = add(D, "decoder", "upT", us[i][0], us[i][2])  # ConvTranspose(stride, kernel, padding), AEKL:66-77
+                b.conv(n + ".conv.conv", in_c, in_c, us[i][1])  # (weight [in, out, k..]: the same shape, both are in_c)
+            elif i != L - 1:
                 n = add(D, "decoder", "up", us[i][0])  # nearest x stride + fixed k3/p1 conv, AEKL:78-86, 99-105
                 b.conv(n + ".conv.conv", in_c, in_c, 3)
         b.norm(add(D, "decoder", "norm"), in_c)
@@ -522,6 +527,11 @@ class AutoencoderKL(nn.Module):
                 x = self_attention(p, name, x, self.groups, self.eps, 1)  # num_head_channels=None -> 1 head, AEKL:235
             elif kind == "norm":
                 x = F.group_norm(x, self.groups, p[name + ".weight"], p[name + ".bias"], self.eps)
+            elif kind == "upT":
+                st_, pd_ = step[2], step[3]
+                op_ = st_ - 1 if isinstance(st_, int) else tuple(int(v) - 1 for v in st_)
+                fn = F.conv_transpose3d if self.sd == 3 else F.conv_transpose2d
+                x = fn(x, p[name + ".conv.conv.weight"], p[name + ".conv.conv.bias"], stride=st_, padding=pd_, output_padding=op_)
             elif kind == "up":
                 sf = step[2] if isinstance(step[2], int) else tuple(float(s) for s in step[2])
                 x = F.interpolate(x, scale_factor=sf, mode="nearest")
