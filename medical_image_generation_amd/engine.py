@@ -46,6 +46,7 @@ GN_BWD_FUSED = _os.environ.get("MI_GN_BWD_FUSED", "0") == "1"
 # 23.35 / 23.36 with the fork for plans of <= 160 workgroups, 23.35 / 23.42 for <= 300: the fork / join edges of 14 layers cost more
 # than the overlap returns (round 2 measured the same for a fork of every layer).
 SIDE_WGRAD = _os.environ.get("MI_SIDE_WGRAD", "0") == "1"
+DGRAD_FIRST = _os.environ.get("MI_DGRAD_FIRST", "0") == "1"  # data gradient before the weight gradient of a conv (default: after)
 SIDE_MAX_WGS = int(_os.environ.get("MI_SIDE_MAX_WGS", "160"))
 _side_streams: dict = {}
 _side_pending: set = set()  # devices whose side stream has work the main stream has not waited for
@@ -388,6 +389,7 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
                 else:
                     plan.wgrad(xin, dy, gw, pn, ps, colsum=d_addvec if d_addvec is not None else ctx.g(name + ".bias"))
 
+            g_early = plan.dgrad(dy) if (DGRAD_FIRST and need_dx) else None  # (A/B: which of the two readers of dy runs first)
             if SIDE_WGRAD and need_dx and bias_grad_like is None and _small_grid(plan):
                 dev, side = dy.device, _side_stream(dy.device)
                 side.wait_stream(torch.cuda.current_stream(dev))  # dy (and everything before it) is ready
@@ -400,7 +402,7 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
             if res is not None:
                 tape.put(res, dy)
             if need_dx:
-                g = plan.dgrad(dy)
+                g = g_early if g_early is not None else plan.dgrad(dy)
                 if norm is not None:
                     other, other2 = tape.take2(x)
                     dx = ops.gn_bwd(g, x, norm, ctx.p(norm.name + ".weight"), silu, ctx.g(norm.name + ".weight"),
