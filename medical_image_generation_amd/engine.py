@@ -37,6 +37,9 @@ FUSE_GN_STATS = ops.FUSE_GN_STATS
 # 64 addresses serialise at the memory side for about as long as the finalize launch took, and every apply thread now starts with a
 # dependent L2 round trip for its coefficients.
 GN_BWD_FUSED = _os.environ.get("MI_GN_BWD_FUSED", "0") == "1"
+# ... or only for tensors of at most this many voxels per image (the coarse levels: few blocks, so few atomics per address; there the
+# finish launch it saves is a large part of the three-launch backward).  0 = off.
+GN_BWD_FUSED_MAXV = int(_os.environ.get("MI_GN_BWD_FUSED_MAXV", "0"))
 
 
 # A/B knob, default OFF: weight gradients of the layers whose kernels cannot fill the chip on a second stream.  A conv's data gradient
@@ -206,10 +209,10 @@ class Ctx:
         self._z64 = None   # zeroed fp64 scratch of this pass (zeros64): cleared by ONE fill, handed out in slices
         self._z64_off = 0
 
-    def zeros64(self, numel, device):
+    def zeros64(self, numel, device, voxels=None):
         """A zeroed fp64 slice for a kernel that accumulates with atomics (the fused GroupNorm backward): carved from a buffer that one
-        fill per pass clears, so that no norm needs a zero-fill node of its own.  None when GN_BWD_FUSED is off."""
-        if not GN_BWD_FUSED:
+        fill per pass clears, so that no norm needs a zero-fill node of its own.  None when the fused form is off for this size."""
+        if not (GN_BWD_FUSED or (voxels is not None and voxels <= GN_BWD_FUSED_MAXV)):
             return None
         numel = (numel + 31) // 32 * 32
         if self._z64 is None or self._z64_off + numel > self._z64.numel():
@@ -406,7 +409,7 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
                 if norm is not None:
                     other, other2 = tape.take2(x)
                     dx = ops.gn_bwd(g, x, norm, ctx.p(norm.name + ".weight"), silu, ctx.g(norm.name + ".weight"),
-                                    ctx.g(norm.name + ".bias"), add=other, add2=other2, sums=ctx.zeros64(2 * x.shape[0] * x.shape[-1], x.device))
+                                    ctx.g(norm.name + ".bias"), add=other, add2=other2, sums=ctx.zeros64(2 * x.shape[0] * x.shape[-1], x.device, x.shape[1] * x.shape[2] * x.shape[3]))
                     tape.grads[id(x)] = dx
                     tape.keep.append(x)
                 else:
@@ -495,7 +498,7 @@ def gn_act(ctx: Ctx, x, st, silu):
                 return
             other, other2 = tape.take2(x)
             dx = ops.gn_bwd(g, x, st, ctx.p(st.name + ".weight"), silu, ctx.g(st.name + ".weight"), ctx.g(st.name + ".bias"), add=other,
-                            add2=other2, sums=ctx.zeros64(2 * x.shape[0] * x.shape[-1], x.device))
+                            add2=other2, sums=ctx.zeros64(2 * x.shape[0] * x.shape[-1], x.device, x.shape[1] * x.shape[2] * x.shape[3]))
             tape.grads[id(x)] = dx
             tape.keep.append(x)
 
@@ -656,7 +659,7 @@ def _attention_param_and_input_grads(ctx, tape, x, name, st, xn, wqkv, dqkv, dy,
     _gemm(dqkv, 3 * c, 0, 0, wqkv_t, 3 * c, 0, 0, dxn, c, 0, 0, b * s, c, 3 * c, 1, 1)
     other = tape.take(x)
     dx = ops.gn_bwd(dxn, x, st, ctx.p(pre + "norm.weight"), False, ctx.g(pre + "norm.weight"), ctx.g(pre + "norm.bias"), add=dy, add2=other,
-                    sums=ctx.zeros64(2 * x.shape[0] * x.shape[-1], x.device))
+                    sums=ctx.zeros64(2 * x.shape[0] * x.shape[-1], x.device, x.shape[1] * x.shape[2] * x.shape[3]))
     tape.grads[id(x)] = dx
     tape.keep.append(x)
 
