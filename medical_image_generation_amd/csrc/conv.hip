@@ -1883,6 +1883,13 @@ struct mi_conv_plan {
   float* d_c1part = nullptr;  // per-workgroup slabs of the single-channel weight-gradient kernel (conv_c1.hip)
   bool v27_fwd = false, v27_dg = false;  // forward / data gradient run on conv27.hip (LDS-DMA kernel); weights packed with perm16
   bool v11_fwd = false, v11_dg = false;  // 1x1x1: forward / data gradient run on conv1x1.hip (streaming GEMM); weights packed with perm16
+  // 1x1x1 convs whose weights do not fit conv1x1.hip's LDS-resident form (shortcut convs of the coarse levels: 512 -> 256 ...): forward and
+  // data gradient on the NT GEMM (gemm.hip) with plain bf16 copies of the weight, [Cout][Cin] and its transpose, refreshed at pack time
+  bool g11 = false;
+  bf16* d_w11 = nullptr;
+  bf16* d_w11t = nullptr;
+  void* d_g11job = nullptr;        // one-entry job table of the single-plan pack (the per-step path is the batch)
+  const float* g11job_w = nullptr;
 };
 
 namespace {
@@ -2257,6 +2264,12 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
     auto chunks_ok = [](int c) { int n = (c + 31) / 32; return n == 1 || n == 2 || n == 3 || n == 4 || n == 6; };
     P->v11_fwd = use11 && k1 && (Cin % 8) == 0 && chunks_ok(Cin) && ((Cout + 31) / 32) * ((Cin + 31) / 32) * 2 <= 96;
     P->v11_dg = use11 && k1 && (Cout % 8) == 0 && chunks_ok(Cout) && ((Cout + 31) / 32) * ((Cin + 31) / 32) * 2 <= 96;
+    static const int use_g11 = env_int("MI_CONV1X1_GEMM", 1);  // 0: the table-driven kernel for those layers (A/B runs)
+    P->g11 = use_g11 && k1 && (!P->v11_fwd || !P->v11_dg) && (Cin % 8) == 0 && (Cout % 8) == 0;
+    if (P->g11 && (hipMalloc((void**)&P->d_w11, (size_t)Cin * Cout * 2) != hipSuccess || hipMalloc((void**)&P->d_w11t, (size_t)Cin * Cout * 2) != hipSuccess)) {
+      mi_conv_plan_destroy(P);
+      return (int)hipErrorOutOfMemory;
+    }
   }
   build_tables(P->fwd, P->g_fwd, P->ncb_fwd, cf, P->f, P->k, true, Cin, Cout, false, P->v27_fwd || P->v11_fwd);
   // dgrad: loader reads dy (Do,Ho,Wo,Cout); outputs the depth image of dx on the (Dp,Hp,Wp) grid with Q*Cin channels
@@ -2352,6 +2365,9 @@ int mi_conv_plan_destroy(mi_conv_plan* P) {
   if (P->d_part) (void)hipFree(P->d_part);
   if (P->d_cspart) (void)hipFree(P->d_cspart);
   if (P->d_c1w) (void)hipFree(P->d_c1w);
+  if (P->d_w11) (void)hipFree(P->d_w11);
+  if (P->d_w11t) (void)hipFree(P->d_w11t);
+  if (P->d_g11job) (void)hipFree(P->d_g11job);
   if (P->d_c1part) (void)hipFree(P->d_c1part);
   if (P->d_xs) (void)hipFree(P->d_xs);
   if (P->d_dxs) (void)hipFree(P->d_dxs);
@@ -2397,6 +2413,40 @@ int mi_conv_plan_out_dims(const mi_conv_plan* P, int* dims3) {
 }
 
 // fp32 master weight [Cout][Cin][kd][kh][kw] -> packed bf16 fragments for forward and dgrad
+}  // extern "C"
+
+// bf16 copies of a 1x1 weight for the GEMM path: o[co][ci] and ot[ci][co]; one block per 32 x 32 tile, all such convs in one launch
+struct G11Job { const float* w; bf16* o; bf16* ot; int Co, Ci, block0, bx; };
+namespace {
+__global__ void __launch_bounds__(256) k_pack_gemm11(const G11Job* __restrict__ jobs, int njobs) {
+  __shared__ float t[32][33];
+  int j = 0;
+  while (j + 1 < njobs && (int)blockIdx.x >= jobs[j + 1].block0) ++j;
+  const G11Job g = jobs[j];
+  const int b = blockIdx.x - g.block0, bi = b % g.bx, bo = b / g.bx;  // tile (co block bo, ci block bi)
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const int co = bo * 32 + r, ci = bi * 32 + tx;
+    const float v = (co < g.Co && ci < g.Ci) ? g.w[(int64_t)co * g.Ci + ci] : 0.f;
+    t[r][tx] = v;
+    if (co < g.Co && ci < g.Ci) g.o[(int64_t)co * g.Ci + ci] = f2bf(v);
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = bi * 32 + r, co = bo * 32 + tx;
+    if (co < g.Co && ci < g.Ci) g.ot[(int64_t)ci * g.Co + co] = f2bf(t[tx][r]);
+  }
+}
+G11Job g11_job(const mi_conv_plan* P, const float* w, int block0) {
+  G11Job g;
+  g.w = w; g.o = P->d_w11; g.ot = P->d_w11t; g.Co = P->Cout; g.Ci = P->Cin; g.block0 = block0; g.bx = (P->Cin + 31) / 32;
+  return g;
+}
+int g11_blocks(const mi_conv_plan* P) { return ((P->Cin + 31) / 32) * ((P->Cout + 31) / 32); }
+}  // namespace
+
+extern "C" {
+
 int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
   if (!P || !w) return MI_ERR_BAD_ARG;
   {
@@ -2408,12 +2458,23 @@ int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
   hipLaunchKernelGGL(k_pack_weights, dim3(((P->fwd.nfrags + P->dg.nfrags) * 64 + 255) / 256), dim3(256), 0, st, w, P->fwd.d_wpk,
                      P->fwd.d_items, P->fwd.nfrags, P->dg.d_wpk, P->dg.d_items, P->dg.nfrags, P->Cout, P->Cin, P->KT, P->d_c1w,
                      P->d_c1w ? 27 * P->Cin * P->Cout : 0);
+  if (P->g11) {  // (synchronous upload of the one-entry job table: not during a capture -- the trainers pack through the batch there)
+    if (!P->d_g11job || P->g11job_w != w) {
+      if (!P->d_g11job && hipMalloc(&P->d_g11job, sizeof(G11Job)) != hipSuccess) return (int)hipErrorOutOfMemory;
+      const G11Job h = g11_job(P, w, 0);
+      if (hipMemcpy(P->d_g11job, &h, sizeof(h), hipMemcpyHostToDevice) != hipSuccess) return (int)hipErrorUnknown;
+      P->g11job_w = w;
+    }
+    hipLaunchKernelGGL(k_pack_gemm11, dim3(g11_blocks(P)), dim3(256), 0, st, (const G11Job*)P->d_g11job, 1);
+  }
   P->c1_packed = true;
   MI_CHECK_LAUNCH();
   return 0;
 }
 
 struct mi_pack_batch {
+  G11Job* d_g11 = nullptr;  // 1x1 convs on the GEMM path: one more launch for all of them
+  int ng11 = 0, g11_blocks = 0;
   PackGroup* d_groups = nullptr;
   int2* d_gtaps = nullptr;
   int ngroups = 0;
@@ -2461,6 +2522,8 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
   size_t lds = 0;
   std::vector<PhasePackJob> phase;
   int phase_blocks = 0;
+  std::vector<G11Job> g11;
+  int g11_nblocks = 0;
   for (int i = 0; i < n; ++i) {
     mi_conv_plan* P = plans[i];
     if (!P || !weights[i]) return MI_ERR_BAD_ARG;
@@ -2469,6 +2532,10 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
         phase.push_back(phase_job(*ps, weights[i], P->Cout, P->Cin, phase_blocks));
         phase_blocks += mi_pack_phase_blocks(ps->nfrags, ps->ncb, ps->nchunks);
       }
+    if (P->g11) {
+      g11.push_back(g11_job(P, weights[i], g11_nblocks));
+      g11_nblocks += g11_blocks(P);
+    }
     if (P->up) P = P->up_inner;  // (its tables pack like any k3 s1 conv's)
     P->c1_packed = true;
     const size_t g0 = groups.size();
@@ -2483,6 +2550,14 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
   mi_pack_batch* B = new mi_pack_batch();
   B->ngroups = (int)groups.size(); B->lds = lds;
   B->nphase = (int)phase.size(); B->phase_blocks = phase_blocks;
+  B->ng11 = (int)g11.size(); B->g11_blocks = g11_nblocks;
+  if (B->ng11) {
+    if (hipMalloc((void**)&B->d_g11, sizeof(G11Job) * g11.size()) != hipSuccess ||
+        hipMemcpy(B->d_g11, g11.data(), sizeof(G11Job) * g11.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      mi_conv_pack_batch_destroy(B);
+      return (int)hipErrorOutOfMemory;
+    }
+  }
   if (B->nphase) {
     if (hipMalloc((void**)&B->d_phase, sizeof(PhasePackJob) * phase.size()) != hipSuccess ||
         hipMemcpy(B->d_phase, phase.data(), sizeof(PhasePackJob) * phase.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -2505,6 +2580,8 @@ int mi_conv_pack_batch_run(mi_pack_batch* B, hipStream_t st) {
   if (!B) return MI_ERR_BAD_ARG;
   if (B->ngroups) hipLaunchKernelGGL(k_pack_groups, dim3(B->ngroups), dim3(256), B->lds, st, B->d_groups, B->d_gtaps);
   MI_CHECK_LAUNCH();
+  if (B->ng11) hipLaunchKernelGGL(k_pack_gemm11, dim3(B->g11_blocks), dim3(256), 0, st, (const G11Job*)B->d_g11, B->ng11);
+  MI_CHECK_LAUNCH();
   if (B->nphase) return mi_launch_pack_phase(B->d_phase, B->nphase, B->phase_blocks, st);
   return 0;
 }
@@ -2513,6 +2590,7 @@ int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
   if (B->d_groups) (void)hipFree(B->d_groups);
   if (B->d_gtaps) (void)hipFree(B->d_gtaps);
   if (B->d_phase) (void)hipFree(B->d_phase);
+  if (B->d_g11) (void)hipFree(B->d_g11);
   delete B;
   return 0;
 }
@@ -2571,6 +2649,10 @@ int mi_conv_fwd(mi_conv_plan* P, const void* x, int x_cs, const float* scale_shi
     a.x_bytes = (unsigned)xb;
   }
   a.perm16 = P->v27_fwd || P->v11_fwd;
+  if (P->g11 && !P->v11_fwd && !scale_shift && !res && (x_cs & 7) == 0 && (y_cs & 7) == 0 && addvec_stride == 0 && !out_stats &&
+      ((uintptr_t)x & 15) == 0 && (int64_t)P->N * P->Do * P->Ho * P->Wo < (1ll << 31))  // y[vox][co] = x[vox][:] . W[co][:] + bias
+    return mi_gemm_nt_bf16(x, x_cs, 0, 0, P->d_w11, P->Cin, 0, 0, y, y_cs, 0, 0, addvec, nullptr, 0, 0, 0, P->N * P->Do * P->Ho * P->Wo, P->Cout, P->Cin, 1, 1,
+                           1.0f, 0, 0, st);
   if (P->v11_fwd && !scale_shift && !res && (x_cs & 7) == 0) {
     const int64_t yb = (int64_t)P->N * P->Do * P->Ho * P->Wo * y_cs * 2;
     a.y_bytes = yb < (1ll << 32) ? (unsigned)yb : 0u;
@@ -2628,6 +2710,10 @@ int mi_conv_dgrad(mi_conv_plan* P, const void* dy, int dy_cs, void* dx, int dx_c
     a.x_bytes = (unsigned)xb;
   }
   a.perm16 = P->v27_dg || P->v11_dg;
+  if (P->g11 && !P->v11_dg && (dy_cs & 7) == 0 && (dx_cs & 7) == 0 && ((uintptr_t)dy & 15) == 0 &&
+      (int64_t)P->N * P->Do * P->Ho * P->Wo < (1ll << 31))  // dx[vox][ci] = dy[vox][:] . W^T[ci][:]
+    return mi_gemm_nt_bf16(dy, dy_cs, 0, 0, P->d_w11t, P->Cout, 0, 0, dx, dx_cs, 0, 0, nullptr, nullptr, 0, 0, 0, P->N * P->Do * P->Ho * P->Wo, P->Cin, P->Cout, 1,
+                           1, 1.0f, 0, 0, st);
   if (P->v11_dg && (dy_cs & 7) == 0) {
     const int64_t yb = (int64_t)P->N * a.Do * a.Ho * a.Wo * a.y_cs * 2;
     a.y_bytes = yb < (1ll << 32) ? (unsigned)yb : 0u;

@@ -160,6 +160,9 @@ CONV_CASES = [
     (2, 64, 32, (8, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # streaming 1x1 kernels: per-image dy column sums, 2 images
     (1, 192, 64, (4, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (1, 32, 96, (4, 8, 9), (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # ragged voxel count
+    (1, 512, 256, (4, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0)),  # weights too wide for the streaming kernel's LDS: forward / dgrad on the NT GEMM
+    (2, 384, 128, (5, 9, 11), (1, 1, 1), (1, 1, 1), (0, 0, 0)),  # ... ragged voxel count, two images
+    (1, 256, 768, (4, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (2, 32, 32, (8, 8, 8), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (1, 64, 64, (6, 10, 12), (3, 3, 3), (2, 2, 2), (1, 1, 1)),
     (1, 32, 32, (8, 8, 4), (3, 3, 1), (2, 2, 1), (1, 1, 0)),
