@@ -1612,6 +1612,84 @@ __global__ void __launch_bounds__(256) k_pack_groups(const PackGroup* __restrict
   }
 }
 
+// Both fragment tables of a conv from ONE read of its weights.  The forward table wants (32 cout x 16 cin) blocks, the data-gradient table
+// (16 cout x 32 cin) blocks of the same tensor: packed group by group every weight was read twice (441 M parameters: 2.0 ms per step of
+// the latent UNet, 2.6 TB/s).  A SUPER-GROUP is the 32 x 32 (cout x cin) block of the torch weight with all its taps -- up to 110 KB of
+// LDS, read with 16-byte loads where the block is 16-byte aligned -- and the (up to four) groups that live in it.
+struct PackSuper {
+  const float* w;
+  int O0, I0, Co_t, Ci_t, KT;
+  int ng;
+  int g[4];  // indices into the group table
+};
+constexpr int kPackSuperT = 1024;  // one block per CU (110 KB of LDS): 16 waves keep enough loads in flight
+__global__ void __launch_bounds__(kPackSuperT) k_pack_super(const PackSuper* __restrict__ supers, const PackGroup* __restrict__ groups,
+                                                    const int2* __restrict__ gtaps) {
+  extern __shared__ float sm[];
+  const PackSuper su = supers[blockIdx.x];
+  const int run = 32 * su.KT, pitch = run + 1;
+  const int nci = su.Ci_t - su.I0 < 32 ? su.Ci_t - su.I0 : 32, nvalid = nci * su.KT;
+  const int nco = su.Co_t - su.O0 < 32 ? su.Co_t - su.O0 : 32;
+  const int64_t row_stride = (int64_t)su.Ci_t * su.KT;
+  const float* base = su.w + ((int64_t)su.O0 * su.Ci_t + su.I0) * su.KT;
+  const bool vec = (((uintptr_t)base & 15) == 0) && (row_stride & 3) == 0 && (nvalid & 3) == 0;
+  if (vec) {
+    const int q = nvalid >> 2, total = nco * q;  // float4 pieces
+    for (int e0 = threadIdx.x; e0 < total; e0 += 5 * kPackSuperT) {
+      f32x4 v[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int e = e0 + u * kPackSuperT, o = e / q, c4 = e - o * q;
+        v[u] = e < total ? *(const f32x4*)(base + o * row_stride + 4 * c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int e = e0 + u * kPackSuperT, o = e / q, c4 = e - o * q;
+        if (e < total) {
+          float* d = sm + o * pitch + 4 * c4;
+          d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+        }
+      }
+    }
+  } else {
+    const int total = nco * nvalid;
+    for (int e0 = threadIdx.x; e0 < total; e0 += 8 * kPackSuperT) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * kPackSuperT, o = e / nvalid, c = e - o * nvalid;
+        v[u] = e < total ? base[o * row_stride + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * kPackSuperT, o = e / nvalid, c = e - o * nvalid;
+        if (e < total) sm[o * pitch + c] = v[u];
+      }
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rho = lane & 31, h = lane >> 5;
+  for (int gi = 0; gi < su.ng; ++gi) {
+    const PackGroup g = groups[su.g[gi]];
+    if (g.c1w)
+      for (int i = threadIdx.x; i < g.c1n; i += kPackSuperT) g.c1w[i] = g.w[i];
+    const int oo = g.o0 - su.O0, io = g.i0 - su.I0;  // this group's corner inside the block (0 or 16)
+    const int crow = g.perm ? 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3) : rho;
+    for (int ti = wave; ti < g.ntaps; ti += kPackSuperT / 64) {
+      const int2 tf = gtaps[g.tap_off + ti];
+      F8 v;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = 8 * h + j;
+        const int o = oo + (g.tr ? k : crow), i = io + (g.tr ? crow : k);
+        v.v[j] = (tf.x >= 0 && o < nco && i < nci) ? sm[o * pitch + i * su.KT + tf.x] : 0.f;
+      }
+      g.out[(int64_t)tf.y * 64 + lane] = pack8(v);
+    }
+  }
+}
+
 // colsum[n * stride + co] += sum_split cs_part[split][n][co]   (stride 0: one row for the whole batch); block = 32 channels x 8 split groups.
 // Rides as extra trailing blocks of the weight-gradient reduce launch (one launch per conv instead of two: ~50 launches of a
 // 5 us latency-bound kernel per step).  part == nullptr: none.
@@ -2473,6 +2551,9 @@ int mi_conv_pack_weights(mi_conv_plan* P, const float* w, hipStream_t st) {
 }
 
 struct mi_pack_batch {
+  PackSuper* d_supers = nullptr;  // groups paired by the 32 x 32 weight block they read (k_pack_super); nsupers == 0: k_pack_groups
+  int nsupers = 0;
+  size_t lds_super = 0;
   G11Job* d_g11 = nullptr;  // 1x1 convs on the GEMM path: one more launch for all of them
   int ng11 = 0, g11_blocks = 0;
   PackGroup* d_groups = nullptr;
@@ -2524,6 +2605,10 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
   int phase_blocks = 0;
   std::vector<G11Job> g11;
   int g11_nblocks = 0;
+  std::vector<PackSuper> supers;
+  size_t lds_super = 0;
+  static const int use_super = env_int("MI_PACK_SUPER", 1);  // 0: one block per group, every weight read once per table (A/B runs)
+  bool super_ok = use_super != 0;
   for (int i = 0; i < n; ++i) {
     mi_conv_plan* P = plans[i];
     if (!P || !weights[i]) return MI_ERR_BAD_ARG;
@@ -2542,6 +2627,28 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
     add_groups(groups, gtaps, P->fwd, weights[i], P);
     add_groups(groups, gtaps, P->dg, weights[i], P);
     if (P->d_c1w && groups.size() > g0) { groups[g0].c1w = P->d_c1w; groups[g0].c1n = 27 * P->Cin * P->Cout; }
+    {  // super-groups of this plan: groups keyed by the 32 x 32 block of the torch weight they read
+      std::unordered_map<int64_t, int> at;
+      for (size_t gi = g0; gi < groups.size(); ++gi) {
+        const PackGroup& g = groups[gi];
+        const int O0 = g.o0 & ~31, I0 = g.i0 & ~31;
+        const int64_t key = ((int64_t)O0 << 32) | (unsigned)I0;
+        auto f = at.find(key);
+        if (f == at.end()) {
+          PackSuper su;
+          memset(&su, 0, sizeof(su));
+          su.w = weights[i]; su.O0 = O0; su.I0 = I0; su.Co_t = P->Cout; su.Ci_t = P->Cin; su.KT = P->KT;
+          at.emplace(key, (int)supers.size());
+          supers.push_back(su);
+          f = at.find(key);
+        }
+        PackSuper& su = supers[(size_t)f->second];
+        if (su.ng < 4) su.g[su.ng++] = (int)gi;
+        else super_ok = false;  // (more than four groups in one block: not a layout this file produces)
+      }
+      const size_t need_su = sizeof(float) * 32 * (size_t)(32 * P->KT + 1);
+      if (need_su > lds_super) lds_super = need_su;
+    }
     const size_t need = sizeof(float) * 32 * (size_t)(16 * P->KT + 1) > sizeof(float) * 16 * (size_t)(32 * P->KT + 1)
                             ? sizeof(float) * 32 * (size_t)(16 * P->KT + 1) : sizeof(float) * 16 * (size_t)(32 * P->KT + 1);
     if (need > lds) lds = need;
@@ -2551,6 +2658,16 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
   B->ngroups = (int)groups.size(); B->lds = lds;
   B->nphase = (int)phase.size(); B->phase_blocks = phase_blocks;
   B->ng11 = (int)g11.size(); B->g11_blocks = g11_nblocks;
+  if (use_super > 1) fprintf(stderr, "[pack batch] %d plans, %zu groups, %zu super-groups, paired: %d, LDS %zu B\n", n, groups.size(), supers.size(), (int)super_ok, lds_super);
+  if (super_ok && !supers.empty() && lds_super <= 150 * 1024) {
+    if (hipMalloc((void**)&B->d_supers, sizeof(PackSuper) * supers.size()) != hipSuccess ||
+        hipMemcpy(B->d_supers, supers.data(), sizeof(PackSuper) * supers.size(), hipMemcpyHostToDevice) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_pack_super, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      mi_conv_pack_batch_destroy(B);
+      return (int)hipErrorOutOfMemory;
+    }
+    B->nsupers = (int)supers.size(); B->lds_super = lds_super;
+  }
   if (B->ng11) {
     if (hipMalloc((void**)&B->d_g11, sizeof(G11Job) * g11.size()) != hipSuccess ||
         hipMemcpy(B->d_g11, g11.data(), sizeof(G11Job) * g11.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -2578,7 +2695,8 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
 }
 int mi_conv_pack_batch_run(mi_pack_batch* B, hipStream_t st) {
   if (!B) return MI_ERR_BAD_ARG;
-  if (B->ngroups) hipLaunchKernelGGL(k_pack_groups, dim3(B->ngroups), dim3(256), B->lds, st, B->d_groups, B->d_gtaps);
+  if (B->nsupers) hipLaunchKernelGGL(k_pack_super, dim3(B->nsupers), dim3(kPackSuperT), B->lds_super, st, B->d_supers, B->d_groups, B->d_gtaps);
+  else if (B->ngroups) hipLaunchKernelGGL(k_pack_groups, dim3(B->ngroups), dim3(256), B->lds, st, B->d_groups, B->d_gtaps);
   MI_CHECK_LAUNCH();
   if (B->ng11) hipLaunchKernelGGL(k_pack_gemm11, dim3(B->g11_blocks), dim3(256), 0, st, (const G11Job*)B->d_g11, B->ng11);
   MI_CHECK_LAUNCH();
@@ -2591,6 +2709,7 @@ int mi_conv_pack_batch_destroy(mi_pack_batch* B) {
   if (B->d_gtaps) (void)hipFree(B->d_gtaps);
   if (B->d_phase) (void)hipFree(B->d_phase);
   if (B->d_g11) (void)hipFree(B->d_g11);
+  if (B->d_supers) (void)hipFree(B->d_supers);
   delete B;
   return 0;
 }
