@@ -160,6 +160,9 @@ CONV_CASES = [
     (2, 64, 32, (8, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # streaming 1x1 kernels: per-image dy column sums, 2 images
     (1, 192, 64, (4, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
     (1, 32, 96, (4, 8, 9), (1, 1, 1), (1, 1, 1), (0, 0, 0)),    # ragged voxel count
+    (1, 512, 512, (4, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),   # one tile = one split, 256 (cout block, cin chunk) pairs
+    (1, 96, 544, (4, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),    # ... 17 cout blocks x 3 cin chunks
+    (1, 40, 72, (4, 8, 8), (3, 3, 3), (1, 1, 1), (1, 1, 1)),     # ... ragged last chunk (8 of 32 channels) and last cout block (8 of 32 rows)
     (1, 512, 256, (4, 8, 8), (1, 1, 1), (1, 1, 1), (0, 0, 0)),  # weights too wide for the streaming kernel's LDS: forward / dgrad on the NT GEMM
     (2, 384, 128, (5, 9, 11), (1, 1, 1), (1, 1, 1), (0, 0, 0)),  # ... ragged voxel count, two images
     (1, 256, 768, (4, 4, 4), (1, 1, 1), (1, 1, 1), (0, 0, 0)),
