@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <unordered_map>
 #include <vector>
 
@@ -1193,6 +1194,14 @@ constexpr int WR_XRING = 88 * 1024;       // 3 groups + the 2-slice copy = 89,60
 constexpr int WR_YB = 16 * 1024;          // dY tile image (two of them)
 constexpr int WR_LDS = WR_XRING + 2 * WR_YB + 64;
 
+#ifdef MI_WG3_DIAG_CLK  // `make diag`: 100 MHz real-time stamps of workgroup 0's phases + the first entry / last exit over all workgroups
+__device__ unsigned long long g_wg3_clk[16];
+__device__ unsigned long long g_wg3_span[6][1024];  // entry / exit / end of compute wave 0's tile loop / its prologue barrier, per workgroup
+#define WG3_STAMP(i) do { if (blockIdx.x == 0 && lane == 0) g_wg3_clk[i] = wall_clock64(); } while (0)
+#else
+#define WG3_STAMP(i) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(768, 3) k_conv_wgrad3(WgradArgs w) {
   constexpr int MAXT = 4, MAXPG = 7, MAXPY = 4;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1214,6 +1223,13 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad3(WgradArgs w) {
     split = blockIdx.x % w.nsplit;
   }
   if (split >= w.nsplit || pair >= w.npairs) return;  // whole workgroup, before any barrier
+#ifdef MI_WG3_DIAG_CLK
+  if (threadIdx.x == 0) {
+    const unsigned long long t = wall_clock64();
+    atomicMin(&g_wg3_clk[14], t);
+    if (blockIdx.x < 1024) g_wg3_span[0][blockIdx.x] = t;
+  }
+#endif
   // run of tiles [t0, tend) in d-fastest order; the splits of one XCD class get neighbouring runs (their h / w halos meet in that L2)
   const int run = (w.nsplit >= 8 && (w.nsplit & 7) == 0) ? (split & 7) * (w.nsplit >> 3) + (split >> 3) : split;
   const int t0 = (int)((int64_t)run * w.ntiles / w.nsplit), tend = (int)((int64_t)(run + 1) * w.ntiles / w.nsplit);  // (nsplit <= ntiles: never empty)
@@ -1231,10 +1247,12 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad3(WgradArgs w) {
 
   if (wave >= 8) {  // ---------------------------------------------------------------- loader waves
     const int first = wave - 8;
+    if (wave == 8) WG3_STAMP(8);
     DmaPieces<MAXPG> dg;
     DmaPieces<MAXPY> dyp;
     dma_init_x<MAXPG>(dg, g, first, 4, 25, lane, a.Hi, a.Wi, a.x_cs, 1, 4);
     dma_init_y<MAXPY>(dyp, g, first, 4, 16, lane, a.Ho, a.Wo, w.dy_cs, 1);
+    if (wave == 8) WG3_STAMP(9);
     auto group = [&](int slot, int dfirst) {  // slices dfirst .. dfirst+3 of the current (n, th, tw) column's halo -> group slot
       dma_issue_x<MAXPG>(dg, a, lds + slot * WR_GROUP, first, 4, 25, lane, n, dfirst + g.hd, th * g.TH, tw * g.TW, src_c0, true, 1, 0, 4);
       if (slot == 0) dma_issue_x<MAXPG>(dg, a, lds + 3 * WR_GROUP, first, 4, 13, lane, n, dfirst + g.hd, th * g.TH, tw * g.TW, src_c0, true, 1, 0, 4);
@@ -1246,7 +1264,9 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad3(WgradArgs w) {
     group(0, td * g.TD - 1);
     group(1, td * g.TD + 3);
     dytile(0);
+    if (wave == 8) WG3_STAMP(10);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wave == 8) WG3_STAMP(11);
     __builtin_amdgcn_s_barrier();  // prologue
     flag_bump(fl_ready, lane);
     for (int t = t0 + 1; t < tend; ++t, ++it) {  // request tile t = number it+1 of the run while number it is being consumed
@@ -1267,6 +1287,7 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad3(WgradArgs w) {
   }
 
   // ------------------------------------------------------------------------------------ compute waves (as k_conv_wgrad2<true>)
+  if (wave == 0) WG3_STAMP(0);
   const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
   const int kh = gq >> 1;
   const int chan_b = ((gq & 1) * 16 + pp * 4) * 2;
@@ -1309,7 +1330,12 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad3(WgradArgs w) {
       if (co < a.Cout) w.cs_part[((int64_t)cs_slab * a.N + img) * a.Cout + co] = 0.f;
     }
   }
+  if (wave == 0) WG3_STAMP(1);
   __builtin_amdgcn_s_barrier();  // prologue: the first tile is in group slots 0, 1 and dY buffer 0
+  if (wave == 0) WG3_STAMP(2);
+#ifdef MI_WG3_DIAG_CLK
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg3_span[3][blockIdx.x] = wall_clock64();
+#endif
   int G = 0, it = 0;
   for (int t = t0; t < tend; ++t, ++it) {
     flag_wait(fl_ready, 4u * (unsigned)(it + 1));
@@ -1329,7 +1355,15 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad3(WgradArgs w) {
     flag_bump(fl_freed, lane);
     if (t + 1 < tend) G += step_digits() ? 1 : 2;
   }
+  if (wave == 0) WG3_STAMP(3);
+#ifdef MI_WG3_DIAG_CLK
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg3_span[2][blockIdx.x] = wall_clock64();
+#endif
   __builtin_amdgcn_s_barrier();  // (pairs with the loaders')
+  if (wave == 0) WG3_STAMP(4);
+#ifdef MI_WG3_DIAG_CLK
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg3_span[4][blockIdx.x] = wall_clock64();
+#endif
   if (cs_wave) cs_flush(cs_n);
   float* out = w.part + (int64_t)split * w.split_stride + w.pair_off[pair];
   const int r = lane & 31, h = lane >> 5;
@@ -1343,6 +1377,17 @@ __global__ void __launch_bounds__(768, 3) k_conv_wgrad3(WgradArgs w) {
       out[((int64_t)ti * 32 + co) * 32 + r] = acc[t][e];
     }
   }
+#ifdef MI_WG3_DIAG_CLK
+  if (wave == 0) WG3_STAMP(5);
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_wg3_span[5][blockIdx.x] = wall_clock64();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (wave == 0) WG3_STAMP(6);
+  if (lane == 0) {
+    const unsigned long long t = wall_clock64();
+    atomicMax(&g_wg3_clk[15], t);
+    if (blockIdx.x < 1024) atomicMax(&g_wg3_span[1][blockIdx.x], t);
+  }
+#endif
 }
 
 // Both instantiations spelled out: with only the implicit ones (the ternary / if-else in the launcher) hipcc 7.2 emitted the host stub
@@ -2395,6 +2440,8 @@ int mi_conv_plan_create(mi_conv_plan** out, int N, int Di, int Hi, int Wi, int C
   }
   static const int old_split = env_int("MI_WGRAD_SPLIT_OLD", 0);  // A/B knob: the round-1 choice
   if (old_split) nsplit = (256 + npairs - 1) / npairs;
+  static const int force_split = env_int("MI_WGRAD_NSPLIT", 0);  // probe knob: this many splits for every layer of at most 64 tiles
+  if (force_split && ntiles <= 64) nsplit = force_split;
   if (nsplit > ntiles) nsplit = ntiles;
   while (nsplit > 1 && (int64_t)nsplit * off * 4 > (256ll << 20)) nsplit /= 2;  // cap the slab at 256 MiB
   if (nsplit < 1) nsplit = 1;
@@ -2980,7 +3027,44 @@ int mi_conv_wgrad(mi_conv_plan* P, const void* x, int x_cs, const float* scale_s
           if (e != hipSuccess) return (int)e;
           attr_r = true;
         }
+#ifdef MI_WG3_DIAG_CLK
+        {
+          unsigned long long h0[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, ~0ull, 0};
+          (void)hipDeviceSynchronize();
+          (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg3_clk), h0, sizeof(h0));
+          static unsigned long long z[6][1024];
+          (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wg3_span), z, sizeof(z));
+        }
+#endif
         hipLaunchKernelGGL(k_conv_wgrad3, grid, dim3(768), (size_t)WR_LDS, st, w);
+#ifdef MI_WG3_DIAG_CLK
+        {
+          unsigned long long h[16];
+          (void)hipDeviceSynchronize();
+          (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wg3_clk), sizeof(h));
+          auto us = [&](int a, int b) { return (double)((long long)h[b] - (long long)h[a]) / 100.0; };
+          fprintf(stderr, "[wgrad3 %d->%d ntiles %d nsplit %d] all workgroups: first entry -> last exit %.2f us | workgroup 0 (from the first entry): entry %.2f, "
+                  "compute wave 0: setup %.2f, prologue barrier %.2f, tiles %.2f, final barrier %.2f, stores issued %.2f, stores landed %.2f | loader wave: "
+                  "descriptors %.2f, prologue issue %.2f, landed %.2f us\n", P->Cin, P->Cout, w.ntiles, w.nsplit, us(14, 15), us(14, 0), us(0, 1), us(1, 2), us(2, 3), us(3, 4),
+                  us(4, 5), us(5, 6), us(8, 9), us(9, 10), us(10, 11));
+          static unsigned long long sp[6][1024];
+          (void)hipMemcpyFromSymbol(sp, HIP_SYMBOL(g_wg3_span), sizeof(sp));
+          std::vector<double> ent, dur, ext, lp, pro, bar, iss;
+          for (unsigned b = 0; b < grid.x && b < 1024; ++b)
+            if (sp[1][b]) { bar.push_back((double)(sp[4][b] - h[14]) / 100.0); iss.push_back((double)(sp[5][b] - h[14]) / 100.0); lp.push_back((double)(sp[2][b] - h[14]) / 100.0); pro.push_back((double)(sp[3][b] - h[14]) / 100.0); ent.push_back((double)(sp[0][b] - h[14]) / 100.0); ext.push_back((double)(sp[1][b] - h[14]) / 100.0); dur.push_back((double)(sp[1][b] - sp[0][b]) / 100.0); }
+          std::sort(ent.begin(), ent.end()); std::sort(dur.begin(), dur.end()); std::sort(ext.begin(), ext.end());
+          std::sort(lp.begin(), lp.end()); std::sort(pro.begin(), pro.end()); std::sort(bar.begin(), bar.end()); std::sort(iss.begin(), iss.end());
+          if (!ent.empty()) fprintf(stderr, "    final barrier passed min %.2f median %.2f max %.2f | wave 0 stores issued min %.2f median %.2f max %.2f us\n", bar.front(), bar[bar.size() / 2],
+                                    bar.back(), iss.front(), iss[iss.size() / 2], iss.back());
+          if (!ent.empty()) fprintf(stderr, "    prologue done min %.2f median %.2f max %.2f | tile loop done min %.2f median %.2f max %.2f us\n", pro.front(), pro[pro.size() / 2], pro.back(),
+                                    lp.front(), lp[lp.size() / 2], lp.back());
+          if (!ent.empty()) {
+            auto qt = [](const std::vector<double>& v, double f) { return v[(size_t)(f * (v.size() - 1))]; };
+            fprintf(stderr, "    %zu workgroups: entry 10%% %.2f median %.2f 90%% %.2f max %.2f | exit min %.2f median %.2f max %.2f | lifetime min %.2f median %.2f 90%% %.2f max %.2f us\n",
+                    ent.size(), qt(ent, 0.1), qt(ent, 0.5), qt(ent, 0.9), ent.back(), ext.front(), qt(ext, 0.5), ext.back(), dur.front(), qt(dur, 0.5), qt(dur, 0.9), dur.back());
+          }
+        }
+#endif
       } else if (geo3) hipLaunchKernelGGL(k_conv_wgrad2<true>, grid, dim3(768), lds2, st, w);
       else hipLaunchKernelGGL(k_conv_wgrad2<false>, grid, dim3(768), lds2, st, w);
 #ifdef MI_WG2_DIAG_BAR

@@ -51,8 +51,14 @@ GN_BWD_FUSED_MAXV = int(_os.environ.get("MI_GN_BWD_FUSED_MAXV", "0"))
 SIDE_WGRAD = _os.environ.get("MI_SIDE_WGRAD", "0") == "1"
 DGRAD_FIRST = _os.environ.get("MI_DGRAD_FIRST", "0") == "1"  # data gradient before the weight gradient of a conv (default: after)
 SIDE_MAX_WGS = int(_os.environ.get("MI_SIDE_MAX_WGS", "160"))
+# A/B knob: the same weight gradients DEFERRED instead -- queued while the backward walks the coarse levels, then launched together on
+# the side stream with ONE fork when the first layer with a chip-filling grid comes up (and one join at the cut mark / the end of the
+# backward): the latency-bound launches of the 16^3 level (each ~40 us for ~10 us of work) run beside the finer levels' kernels.
+DEFER_WGRAD = _os.environ.get("MI_DEFER_WGRAD", "0") == "1"
+DEFER_MAX_TILES = int(_os.environ.get("MI_DEFER_MAX_TILES", "64"))  # layers of at most this many 4 x 8 x 8 output tiles are queued
 _side_streams: dict = {}
 _side_pending: set = set()  # devices whose side stream has work the main stream has not waited for
+_deferred: dict = {}        # device index -> [(closure, tensors it reads)] in backward order
 
 
 def _dev_index(device):
@@ -68,18 +74,44 @@ def _side_stream(device):
     return st
 
 
+def flush_deferred(device):
+    """Launch the queued weight gradients on the side stream, behind everything the current stream holds so far."""
+    i = _dev_index(device)
+    q = _deferred.get(i)
+    if not q:
+        return
+    side = _side_stream(i)
+    side.wait_stream(torch.cuda.current_stream(i))
+    with torch.cuda.stream(side):
+        for fn, _ in q:
+            fn()
+    for _, tensors in q:
+        for t in tensors:
+            t.record_stream(side)  # (freed blocks must not be handed out again under the side kernels)
+    q.clear()
+    _side_pending.add(i)
+
+
 def join_side(device):
     """The current stream waits for everything forked onto the side stream (before anything reads a weight / bias gradient)."""
     i = _dev_index(device)
+    flush_deferred(i)
     if i in _side_pending:
         torch.cuda.current_stream(i).wait_stream(_side_stream(i))
         _side_pending.discard(i)
 
 
-def _small_grid(plan):
+def _tiles(plan):
     od, oh, ow = plan.out_dims if not isinstance(plan, ops.UpConvPlan) else plan.dims
-    tiles = plan.n * ((od + 3) // 4) * ((oh + 7) // 8) * ((ow + 7) // 8)
-    return od > 1 and tiles * ((max(plan.cin, plan.cout) + 31) // 32) <= SIDE_MAX_WGS
+    return plan.n * ((od + 3) // 4) * ((oh + 7) // 8) * ((ow + 7) // 8)
+
+
+def _small_grid(plan):
+    return plan.out_dims[0] > 1 and _tiles(plan) * ((max(plan.cin, plan.cout) + 31) // 32) <= SIDE_MAX_WGS
+
+
+def _coarse(plan):
+    return plan.out_dims[0] > 1 and _tiles(plan) <= DEFER_MAX_TILES
 
 
 # --------------------------------------------------------------------------------------------- parameters
@@ -393,7 +425,14 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
                     plan.wgrad(xin, dy, gw, pn, ps, colsum=d_addvec if d_addvec is not None else ctx.g(name + ".bias"))
 
             g_early = plan.dgrad(dy) if (DGRAD_FIRST and need_dx) else None  # (A/B: which of the two readers of dy runs first)
-            if SIDE_WGRAD and need_dx and bias_grad_like is None and _small_grid(plan):
+            di = _dev_index(dy.device)
+            if DEFER_WGRAD and need_dx and (_coarse(plan) or (bias_grad_like is not None and _deferred.get(di))):
+                # (a shortcut conv copies the bias gradient its block's conv2 produces: it queues up behind a queued conv2)
+                _deferred.setdefault(di, []).append((wgrad, (xin, dy)))
+            elif DEFER_WGRAD and _deferred.get(di):
+                flush_deferred(di)
+                wgrad()
+            elif SIDE_WGRAD and need_dx and bias_grad_like is None and _small_grid(plan):
                 dev, side = dy.device, _side_stream(dy.device)
                 side.wait_stream(torch.cuda.current_stream(dev))  # dy (and everything before it) is ready
                 with torch.cuda.stream(side):
