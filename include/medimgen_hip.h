@@ -196,6 +196,33 @@ int mi_avgpool_bwd(const void* dy, void* dx, int N, int D, int H, int W, int C, 
 int mi_crop_pad(const void* src, int src_is_f16, int C, int D, int H, int W, const int lo[3], float* out, int oD, int oH, int oW,
                 float pad_value, int flip_mask, float scale, int clamp01, hipStream_t stream);
 
+/* ---- training-time augmentation on patches resident in HBM: the transform list of define_nnunet_transformations
+ * (medimgen/data_processing.py:748-859; its parameters come from MedicalDataset's soft setting, :399-416).  The transforms are
+ * third-party batchgeneratorsv2 classes (absent from /root/reference: PARITY UNPINNED, restated in oracle/data.py).  Every call works on
+ * ONE (sample, channel) plane of D*H*W fp32 voxels (2-D: D = 1).
+ *   mi_aug_plane_stats: stats[4] = {min, max, mean, std (Bessel)} of the plane, left on the device for the calls below;
+ *                       workspace >= mi_aug_stats_workspace_bytes()
+ *   mi_aug_pointwise (in place), op =
+ *     MI_AUG_SCALE          x * p0                                             MultiplicativeBrightnessTransform (:790-797)
+ *     MI_AUG_CONTRAST       clamp((x - mean) p0 + mean, min, max)   [stats_a]  ContrastTransform(preserve_range=True) (:798-806)
+ *     MI_AUG_GAMMA          ((x - min) / max(range, 1e-7))^p0 range + min [stats_a]   GammaTransform(p_invert_image=0) (:829-838)
+ *     MI_AUG_RESTORE_STATS  (x - mean_a) std_b / max(std_a, 1e-7) + mean_b  [stats_a = now, stats_b = before]   its p_retain_stats tail
+ *     MI_AUG_ADD_NOISE      x + p0 * aux[i]                                    GaussianNoiseTransform (:771-778), aux = N(0, 1) plane
+ *     MI_AUG_CLAMP01        clamp(x, 0, 1)                                     MedicalDataset.__getitem__ (:595)
+ *   mi_aug_blur_axis: one axis (0 / 1 / 2 = D / H / W) of the separable GaussianBlurTransform (:779-789); taps_host: odd count
+ *                     <= 33, host memory, copied into the launch; reflect padding
+ *   mi_aug_lowres: SimulateLowResolutionTransform (:807-817): nearest-exact resampling to (lD, lH, lW) and linear resampling back,
+ *                  as one gather
+ *   mi_aug_affine_sample: SpatialTransform without elastic deformation (:766-773): y[o] = trilinear(x, A (o - c_out) + c_in), zeros
+ *                  outside, c = (extent - 1) / 2; a_host: row-major 3x3 in host memory ---------------------------------------- */
+enum { MI_AUG_SCALE = 0, MI_AUG_CONTRAST = 1, MI_AUG_GAMMA = 2, MI_AUG_RESTORE_STATS = 3, MI_AUG_ADD_NOISE = 4, MI_AUG_CLAMP01 = 5 };
+int64_t mi_aug_stats_workspace_bytes(void);
+int mi_aug_plane_stats(const float* x, int64_t V, float* stats, float* workspace, hipStream_t stream);
+int mi_aug_pointwise(float* x, int64_t V, int op, float p0, const float* stats_a, const float* stats_b, const float* aux, hipStream_t stream);
+int mi_aug_blur_axis(const float* x, float* y, int D, int H, int W, int axis, const float* taps_host, int ntaps, hipStream_t stream);
+int mi_aug_lowres(const float* x, float* y, int D, int H, int W, int lD, int lH, int lW, hipStream_t stream);
+int mi_aug_affine_sample(const float* x, float* y, int D, int H, int W, int oD, int oH, int oW, const float* a_host, hipStream_t stream);
+
 /* ---- PatchDiscriminator path of the autoencoder's GAN step (train_autoencoder.py:371-397 train_discriminator_step, :416-423 the
  * generator's adversarial term, :600 `PatchDiscriminator(**discriminator_params)`; third-party `generative` classes: PARITY UNPINNED).
  * Its k4 convs (stride 2 / 1, padding 1) are lowered to mi_gemm_nt_bf16 through an explicit patch matrix:

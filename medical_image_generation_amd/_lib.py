@@ -74,6 +74,12 @@ _SIGS = {
     "mi_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_crop_pad": [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p],
+    "mi_aug_stats_workspace_bytes": [],
+    "mi_aug_plane_stats": [_p, _l, _p, _p, _p],
+    "mi_aug_pointwise": [_p, _l, _i, _f, _p, _p, _p, _p],
+    "mi_aug_blur_axis": [_p, _p, _i, _i, _i, _i, _p, _i, _p],
+    "mi_aug_lowres": [_p, _p, _i, _i, _i, _i, _i, _i, _p],
+    "mi_aug_affine_sample": [_p, _p, _i, _i, _i, _i, _i, _i, _p, _p],
     "mi_im2col3d": [_p, _i, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "mi_col2im3d": [_p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p],
     "mi_disc_pack_weights": [_p, _p, _p, _i, _i, _i, _i, _p],
@@ -94,14 +100,14 @@ _SIGS = {
     "mi_axpy_f32": [_p, _p, _f, _l, _p],
     "mi_scale_f32": [_p, _f, _l, _p],
 }
-_RET = {"mi_gn_workspace_bytes": _l, "mi_attn_workspace_bytes": _l}
-_NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes", "mi_attn_supported", "mi_attn_workspace_bytes", "mi_conv_fwd_stats_chunks"}
+_RET = {"mi_gn_workspace_bytes": _l, "mi_attn_workspace_bytes": _l, "mi_aug_stats_workspace_bytes": _l}
+_NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes", "mi_aug_stats_workspace_bytes", "mi_attn_supported", "mi_attn_workspace_bytes", "mi_conv_fwd_stats_chunks"}
 
 _lib = None
 # Version of the C ABI this binding was written against (csrc/api.hip: mi_abi_version).  Entry points have changed their argument
 # lists under unchanged names between versions, and *.so files are not tracked by git: a stale library (or an MI_LIB_PATH pointing at
 # an old ablation build) resolves every symbol and then reads shifted arguments.  load() refuses it.
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def exported_symbols() -> list[str]:

@@ -1,3 +1,3 @@
 #include "common.h"
 #include "medimgen_hip.h"
-extern "C" int mi_abi_version(void) { return 7; }
+extern "C" int mi_abi_version(void) { return 8; }

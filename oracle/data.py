@@ -92,3 +92,81 @@ def batch_sample_order(n_items: int, batch_size: int, number_of_steps: int = 250
         order.extend(available[:batch_size])
         available = available[batch_size:]
     return [[(i, s) for i, s in enumerate(order[k * batch_size:(k + 1) * batch_size])] for k in range(number_of_steps)]
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The transform list of define_nnunet_transformations (DATA:748-859).  The classes are batchgeneratorsv2's (third-party, absent from
+# /root/reference and from this image): PARITY UNPINNED.  Each function states ONE transform's arithmetic for given parameters with
+# torch's own CPU ops (F.pad / conv, F.interpolate, F.grid_sample), which is what that package calls; the draws are the caller's.
+def _torch():
+    import torch
+    import torch.nn.functional as F
+    return torch, F
+
+
+def aug_contrast(plane, factor):
+    """ContrastTransform(preserve_range=True) on one channel."""
+    mean, lo, hi = plane.mean(), plane.min(), plane.max()
+    return ((plane - mean) * factor + mean).clamp(lo, hi)
+
+
+def aug_gamma(plane, gamma, invert=False, retain_stats=True):
+    """GammaTransform on one channel."""
+    torch, _ = _torch()
+    x = -plane if invert else plane.clone()
+    mean, std = x.mean(), x.std()
+    lo = x.min()
+    rng = x.max() - lo
+    x = torch.pow((x - lo) / rng.clamp(min=1e-7), gamma) * rng + lo
+    if retain_stats:
+        x = (x - x.mean()) * (std / x.std().clamp(min=1e-7)) + mean
+    return -x if invert else x
+
+
+def aug_gaussian_taps(sigma, truncate=6.0):
+    torch, _ = _torch()
+    k = int(round(sigma * truncate + 0.5))
+    k += 1 - k % 2
+    ax = torch.arange(k, dtype=torch.float32) - k // 2
+    w = torch.exp(-0.5 * (ax / sigma) ** 2)
+    return w / w.sum()
+
+
+def aug_blur(plane, sigmas):
+    """GaussianBlurTransform on one channel: separable, one sigma per spatial axis, reflect padding."""
+    torch, F = _torch()
+    x = plane.clone()
+    nd = x.dim()
+    for ax, sigma in enumerate(sigmas):
+        w = aug_gaussian_taps(sigma)
+        r = len(w) // 2
+        xm = x.movedim(ax, -1)
+        shp = xm.shape
+        rows = F.pad(xm.reshape(-1, 1, shp[-1]), (r, r), mode="reflect")
+        x = F.conv1d(rows, w.view(1, 1, -1)).reshape(shp).movedim(-1, ax)
+    assert x.dim() == nd
+    return x
+
+
+def aug_lowres(plane, low_shape):
+    """SimulateLowResolutionTransform on one channel: nearest-exact down to low_shape, (bi/tri)linear back."""
+    _, F = _torch()
+    mode = {2: "bilinear", 3: "trilinear"}[plane.dim()]
+    down = F.interpolate(plane[None, None], size=tuple(low_shape), mode="nearest-exact")
+    return F.interpolate(down, size=tuple(plane.shape), mode=mode)[0, 0]
+
+
+def aug_affine(plane, matrix, out_shape=None):
+    """SpatialTransform without deformation on one channel: centred output grid -> source = matrix @ g + centre, sampled with
+    grid_sample(bilinear, zeros, align_corners=False).  `matrix` acts on (d, h, w) (2-D: embed as [1, H, W])."""
+    torch, F = _torch()
+    x = plane if plane.dim() == 3 else plane[None]
+    out_shape = tuple(out_shape or x.shape)
+    m = torch.as_tensor(matrix, dtype=torch.float32)
+    axes = [torch.arange(n, dtype=torch.float32) - (n - 1) / 2 for n in out_shape]
+    g = torch.stack(torch.meshgrid(*axes, indexing="ij"), -1)  # [..., 3] centred (d, h, w)
+    src = g @ m.T + torch.tensor([(n - 1) / 2 for n in x.shape])
+    # voxel index p <-> normalised coordinate (2 p + 1) / n - 1 under align_corners=False; grid_sample wants (w, h, d) order
+    norm = (2 * src + 1) / torch.tensor([float(n) for n in x.shape]) - 1
+    y = F.grid_sample(x[None, None], norm.flip(-1)[None], mode="bilinear", padding_mode="zeros", align_corners=False)[0, 0]
+    return y if plane.dim() == 3 else y[0]

@@ -138,3 +138,37 @@ def test_batch_order_uses_every_sample_before_repeating():
     first_round = [s for b in got[:2] for _, s in b]
     assert len(set(first_round)) == 8  # no repeats while unused samples remain
     assert list(BatchOrder(5, 2, 3, shuffle=False)) == [[(0, 0), (1, 1)], [(0, 2), (1, 3)], [(0, 0), (1, 1)]]
+
+
+def test_augmentation_host_logic():
+    """Host side of the GPU transform chain (medical_image_generation_amd/augment.py): samplers, filter taps, the affine, the list
+    define_nnunet_transformations builds from the soft setting (DATA:748-859, 399-424).  No kernel runs here."""
+    import torch
+    from medical_image_generation_amd import augment as A
+    np.random.seed(0)
+    draws = np.array([A.BGContrast((0.9, 1.1))() for _ in range(4000)])
+    assert draws.min() >= 0.9 and draws.max() <= 1.1 and abs((draws < 1).mean() - 0.5) < 0.05
+    only_up = np.array([A.BGContrast((1.0, 1.5))() for _ in range(200)])
+    assert only_up.min() >= 1.0
+    for sigma in (0.5, 0.7, 1.0):
+        t = A.gaussian_taps(sigma)
+        assert len(t) % 2 == 1 and len(t) == len(od.aug_gaussian_taps(sigma)) and abs(t.sum() - 1) < 1e-6
+        assert np.allclose(t, od.aug_gaussian_taps(sigma).numpy(), atol=1e-7)
+    assert np.array_equal(A.affine_matrix([0, 0, 0], [1, 1, 1]), np.eye(3, dtype=np.float32))
+    m = A.affine_matrix([0.1, 0, 0], [1.1, 1.1, 1.1])  # about the depth axis: d is only scaled, (h, w) rotate
+    assert np.allclose(m[0], [1.1, 0, 0]) and np.allclose(m @ m.T, 1.21 * np.eye(3), atol=1e-6)
+    args = dict(patch_size=(8, 16, 16), rotation=True, scaling=True, mirror=True, gaussian_noise=False, gaussian_blur=True, brightness=True,
+                contrast=False, low_resolution=False, gamma=True, dummy_2d=False)
+    p = A.soft_setting(args, dim=3)
+    assert p["mirror_axes"] == (2,) and p["scaling_range"] == p["brightness_range"] == p["gamma_range"] == (0.9, 1.1) and p["contrast_range"] is None
+    angles = [[p["rot_for_da"](image=None, dim=d) for d in range(3)] for _ in range(50)]
+    assert all(a[1] == 0 and a[2] == 0 and abs(a[0]) <= 0.174533 for a in angles) and any(a[0] != 0 for a in angles)
+    assert A.soft_setting(args, dim=2)["mirror_axes"] == (1,)
+    chain = A.define_nnunet_transformations(p)
+    kinds = [type(getattr(t, "transform", t)).__name__ for t in chain.transforms]
+    assert kinds == ["SpatialTransform", "GaussianBlurTransform", "MultiplicativeBrightnessTransform", "GammaTransform", "GammaTransform",
+                     "MirrorTransform"]
+    with pytest.raises(RuntimeError):  # no CPU fallback
+        chain(image=torch.zeros(1, 8, 16, 16))
+    with pytest.raises(NotImplementedError):
+        A.define_nnunet_transformations(dict(p, dummy_2d=True))
