@@ -78,6 +78,13 @@ class ResidentDataset:
         self.class_locations[name] = class_locations
         self.ids.append(name)
 
+    def add_case(self, data_path, name):
+        """One preprocessed case from disk, as MedicalDataset.load_image finds it (DATA:535-561: <name>.zarr, .npy or .npz, properties
+        in <name>.pkl): read once on the host (volume_io) and uploaded."""
+        from .volume_io import load_image
+        image, properties = load_image(data_path, name)
+        self.add(name, np.asarray(image), properties.get("class_locations"))
+
     def __len__(self):
         return len(self.ids)
 

@@ -172,3 +172,107 @@ def test_augmentation_host_logic():
         chain(image=torch.zeros(1, 8, 16, 16))
     with pytest.raises(NotImplementedError):
         A.define_nnunet_transformations(dict(p, dummy_2d=True))
+
+
+# ---- reading the reference's preprocessed cases (medical_image_generation_amd/volume_io.py).  zarr / numcodecs / blosc are absent:
+# the chunk files below are written by an encoder stated from the published Blosc-1 chunk format and zarr v2 layout (PARITY UNPINNED).
+def _blosc_frame(data: bytes, typesize: int, shuffle: int, blocksize: int, cname="zstd", split=False) -> bytes:
+    import struct
+    import zlib as _z
+
+    import pyarrow as pa
+    code = {"zlib": 3, "zstd": 4}[cname]
+    comp = (lambda b: _z.compress(b)) if cname == "zlib" else (lambda b: pa.Codec("zstd").compress(b, asbytes=True))
+    nbytes = len(data)
+    nblocks = (nbytes + blocksize - 1) // blocksize
+    flags = {0: 0, 1: 0x01, 2: 0x04}[shuffle] | (0 if split else 0x10) | (code << 5)
+    body, starts = b"", []
+    for b in range(nblocks):
+        blk = data[b * blocksize:(b + 1) * blocksize]
+        n = len(blk) // typesize
+        if shuffle == 1 and typesize > 1:
+            blk = np.frombuffer(blk, np.uint8, n * typesize).reshape(n, typesize).T.tobytes() + blk[n * typesize:]
+        elif shuffle == 2:
+            n8 = n // 8 * 8
+            if n8:
+                e = np.frombuffer(blk, np.uint8, n8 * typesize).reshape(n8, typesize, 1)
+                bits = np.unpackbits(e, axis=-1, bitorder="little")           # [element][byte][bit]
+                rows = np.packbits(bits.transpose(1, 2, 0), axis=-1, bitorder="little")  # [byte][bit][n/8]
+                blk = rows.tobytes() + blk[n8 * typesize:]
+        starts.append(16 + 4 * nblocks + len(body))
+        full = len(blk) == blocksize
+        nsplits = typesize if (split and full and typesize <= 16 and blocksize // typesize >= 128) else 1
+        ne = len(blk) // nsplits
+        for j in range(nsplits):
+            part = blk[j * ne:(j + 1) * ne]
+            c = comp(part)
+            if len(c) >= len(part):
+                c = part  # incompressible stream: stored, flagged by its size
+            body += struct.pack("<i", len(c)) + c
+    head = bytes([2, 1, flags, typesize]) + struct.pack("<III", nbytes, blocksize, 16 + 4 * nblocks + len(body))
+    return head + struct.pack(f"<{nblocks}i", *starts) + body
+
+
+@pytest.mark.parametrize("shuffle,split,cname", [(2, False, "zstd"), (1, True, "zstd"), (0, False, "zlib"), (2, True, "zlib")])
+def test_blosc_chunks_decode(shuffle, split, cname):
+    from medical_image_generation_amd import volume_io as vio
+    rng = np.random.default_rng(shuffle)
+    for n, typesize, blocksize in [(1000, 4, 1024), (4099, 4, 2048), (13, 4, 4096), (700, 2, 512), (257, 1, 256), (5000, 8, 8192)]:
+        smooth = (np.cumsum(rng.integers(-3, 4, n)) % 251).astype({1: np.uint8, 2: np.uint16, 4: np.float32, 8: np.float64}[typesize])
+        data = smooth.tobytes() + bytes(rng.integers(0, 255, rng.integers(0, typesize)).astype(np.uint8))  # ragged tail
+        assert vio.blosc_decompress(_blosc_frame(data, typesize, shuffle, blocksize, cname, split)) == data
+    stored = bytes([2, 1, 0x02, 4]) + np.array([8, 8, 24], "<u4").tobytes() + b"abcdefgh"
+    assert vio.blosc_decompress(stored) == b"abcdefgh"
+    with pytest.raises(ValueError):
+        vio.blosc_decompress(b"\x02\x01")
+
+
+def test_preprocessed_case_is_read_like_load_image(tmp_path):
+    """<id>.zarr/image with chunks (1, 1, H, W), Blosc(zstd, bitshuffle) (configuration.py:1403-1412) + <id>.pkl; .npy / .npz fallbacks
+    (DATA:535-561)."""
+    import json
+    import pickle
+
+    from medical_image_generation_amd import volume_io as vio
+    rng = np.random.default_rng(0)
+    vol = rng.uniform(0, 1, (2, 5, 12, 9)).astype(np.float32)
+    arr = tmp_path / "caseA.zarr" / "image"
+    arr.mkdir(parents=True)
+    (tmp_path / "caseA.zarr" / ".zgroup").write_text(json.dumps({"zarr_format": 2}))
+    chunks = (1, 1, 8, 9)  # H not a multiple of the chunk: edge chunks are stored whole, padded with the fill value
+    (arr / ".zarray").write_text(json.dumps({"zarr_format": 2, "shape": list(vol.shape), "chunks": list(chunks), "dtype": "<f4", "order": "C",
+                                            "fill_value": 0.0, "filters": None,
+                                            "compressor": {"id": "blosc", "cname": "zstd", "clevel": 5, "shuffle": 2, "blocksize": 0}}))
+    for c in range(2):
+        for z in range(5):
+            for hb in range(2):
+                if (c, z, hb) == (1, 3, 1):
+                    continue  # a chunk that was never written reads as fill_value
+                tile = np.zeros(chunks, np.float32)
+                part = vol[c, z, hb * 8:(hb + 1) * 8]
+                tile[0, 0, :part.shape[0]] = part
+                (arr / f"{c}.{z}.{hb}.0").write_bytes(_blosc_frame(tile.tobytes(), 4, 2, 128))
+    locs = {1: np.array([[0, 1, 2, 3], [1, 4, 11, 8]]), 2: np.zeros((0, 4), np.int64)}
+    with open(tmp_path / "caseA.pkl", "wb") as f:
+        pickle.dump({"class_locations": locs, "spacing": [1.0, 0.5, 0.5]}, f)
+    image, props = vio.load_image(str(tmp_path), "caseA")
+    want = vol.copy()
+    want[1, 3, 8:] = 0
+    assert image.dtype == np.float32 and np.array_equal(image, want)
+    assert np.array_equal(props["class_locations"][1], locs[1]) and props["spacing"] == [1.0, 0.5, 0.5]
+    np.save(tmp_path / "caseB.npy", vol)
+    np.savez_compressed(tmp_path / "caseC.npz", data=vol)
+    assert np.array_equal(vio.load_image(str(tmp_path), "caseB")[0], vol) and np.array_equal(vio.load_image(str(tmp_path), "caseC")[0], vol)
+    (tmp_path / "caseD.b2nd").write_bytes(b"")
+    with pytest.raises(NotImplementedError):
+        vio.load_image(str(tmp_path), "caseD")
+    with pytest.raises(FileNotFoundError):
+        vio.load_image(str(tmp_path), "caseE")
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("constructed from a properties file",))
+    with open(tmp_path / "caseB.pkl", "wb") as f:
+        pickle.dump({"x": Evil()}, f)
+    with pytest.raises(pickle.UnpicklingError):
+        vio.load_image(str(tmp_path), "caseB")
