@@ -271,6 +271,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 is still timing the roofline kernels when the others get here: tear the group down together
         dist.destroy_process_group()
 
 

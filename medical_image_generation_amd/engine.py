@@ -49,6 +49,11 @@ GN_BWD_FUSED_MAXV = int(_os.environ.get("MI_GN_BWD_FUSED_MAXV", "0"))
 # 23.35 / 23.36 with the fork for plans of <= 160 workgroups, 23.35 / 23.42 for <= 300: the fork / join edges of 14 layers cost more
 # than the overlap returns (round 2 measured the same for a fork of every layer).
 SIDE_WGRAD = _os.environ.get("MI_SIDE_WGRAD", "0") == "1"
+# MI_SIDE_WGRAD=2: the OTHER overlap -- chip-filling layers only.  A conv's weight gradient (MFMA-bound, one persistent workgroup of 168
+# registers x 8 waves per CU: room for other waves beside it) is forked BEHIND its data gradient, so that it runs beside the GroupNorm
+# backward of the conv's input (HBM-bound streaming kernels without LDS) instead of beside the data gradient (which needs the same LDS).
+SIDE_BESIDE_NORM = _os.environ.get("MI_SIDE_WGRAD", "0") == "2"
+SIDE_MIN_WGS = int(_os.environ.get("MI_SIDE_MIN_WGS", "256"))
 DGRAD_FIRST = _os.environ.get("MI_DGRAD_FIRST", "0") == "1"  # data gradient before the weight gradient of a conv (default: after)
 SIDE_MAX_WGS = int(_os.environ.get("MI_SIDE_MAX_WGS", "160"))
 # A/B knob: the same weight gradients DEFERRED instead -- queued while the backward walks the coarse levels, then launched together on
@@ -424,15 +429,19 @@ def conv(ctx: Ctx, x, name, kernel, stride, padding, norm=None, silu=False, addv
                 else:
                     plan.wgrad(xin, dy, gw, pn, ps, colsum=d_addvec if d_addvec is not None else ctx.g(name + ".bias"))
 
-            g_early = plan.dgrad(dy) if (DGRAD_FIRST and need_dx) else None  # (A/B: which of the two readers of dy runs first)
+            beside_norm = (SIDE_BESIDE_NORM and need_dx and norm is not None and plan.out_dims[0] > 1 and
+                           _tiles(plan) * ((max(plan.cin, plan.cout) + 31) // 32) >= SIDE_MIN_WGS)
+            g_early = plan.dgrad(dy) if ((DGRAD_FIRST or beside_norm) and need_dx) else None  # (A/B: which of the two readers of dy runs first)
             di = _dev_index(dy.device)
+            if SIDE_BESIDE_NORM and not beside_norm and bias_grad_like is not None:
+                join_side(dy.device)  # (the bias gradient this layer copies may still be in flight on the side stream)
             if DEFER_WGRAD and need_dx and (_coarse(plan) or (bias_grad_like is not None and _deferred.get(di))):
                 # (a shortcut conv copies the bias gradient its block's conv2 produces: it queues up behind a queued conv2)
                 _deferred.setdefault(di, []).append((wgrad, (xin, dy)))
             elif DEFER_WGRAD and _deferred.get(di):
                 flush_deferred(di)
                 wgrad()
-            elif SIDE_WGRAD and need_dx and bias_grad_like is None and _small_grid(plan):
+            elif beside_norm or (SIDE_WGRAD and need_dx and bias_grad_like is None and _small_grid(plan)):
                 dev, side = dy.device, _side_stream(dy.device)
                 side.wait_stream(torch.cuda.current_stream(dev))  # dy (and everything before it) is ready
                 with torch.cuda.stream(side):
