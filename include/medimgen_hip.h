@@ -73,6 +73,8 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
  * -- [N][C][2] fp64, ZERO on entry (the caller takes it from a buffer it clears once per step) -- with hardware fp64 atomics, and the
  * apply pass derives the per-(image, group) coefficients and the gamma / beta gradients from those sums itself: no finalize launch in
  * the dependency chain of every norm.  Same results as mi_gn_bwd up to the summation order of the block totals (fp64). */
+#define MI_GN_FUSED_REPLICAS 16 /* sums_zeroed holds MI_GN_FUSED_REPLICAS * N * C * 2 doubles: the blocks of the partial pass spread their
+                                 * atomics over up to that many [N][C][2] records, the apply pass folds them in a fixed order */
 int mi_gn_bwd_fused(const void* g, int g_cstride, const void* x, int x_cstride, int N, int64_t V, int C, int G, const float* gamma,
                     const float* scale_shift, const float* mean_rstd, int silu, const void* add, int add_cstride, const void* add2,
                     int add2_cstride, void* dx, int dx_cstride, float* dgamma, float* dbeta, double* sums_zeroed, hipStream_t stream);

@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(kT) k_gn_apply(const bf16* __restrict__ x, int
 template <int ACT>
 __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ g, int gcs, const bf16* __restrict__ x, int xcs,
                                                        const float* __restrict__ scale_shift, float* __restrict__ partial, int C,
-                                                       int64_t V, int64_t vchunk, int sweep, double* __restrict__ sums64) {
+                                                       int64_t V, int64_t vchunk, int sweep, double* __restrict__ sums64, int nrep) {
   extern __shared__ float sm[];
   const int C8 = C / 8, rows = kT / C8;
   const int cg = threadIdx.x % C8, r = threadIdx.x / C8;
@@ -270,8 +270,10 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_partial(const bf16* __restrict__ 
       }
     }
   }
+  // fused form: the block's totals go to replica (block % nrep) of the image's sums -- 1024 blocks adding into ONE [C][2] record
+  // serialise on its few cache lines (round 3: +1.0 ms per step); nrep records cut every address's queue by nrep
   block_fold(s1, s2, sm, partial + (int64_t)n * gridDim.x * C * 2, gridDim.x, blockIdx.x, C, C8, rows, r, cg,
-             sums64 ? sums64 + (int64_t)n * C * 2 : nullptr);
+             sums64 ? sums64 + ((int64_t)(blockIdx.x % nrep) * gridDim.y + n) * C * 2 : nullptr);
 }
 
 // per (n, g): coefficients of dx = a*du + b*x + c per channel, and the affine-parameter gradients
@@ -362,7 +364,8 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
                                                      bf16* __restrict__ dx, int dcs, int C8, int64_t V, int rev,
                                                      const double* __restrict__ sums64, const float* __restrict__ gamma,
                                                      const float* __restrict__ mean_rstd, int G, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta) {
+                                                     float* __restrict__ dbeta, int nrep) {
+  extern __shared__ double ssum[];  // fused form only: this image's [C][2] sums, replicas folded in a fixed order
   const int C = C8 * 8;
   const int tid = blockIdx.x * kT + threadIdx.x;
   const int cg = tid % C8, R = gridDim.x * kT / C8;
@@ -375,7 +378,13 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
     // in the dependency chain of every norm (51 launches of ~9 us per C4 step)
     const int cpg = C / G;
     const double m = (double)V * cpg;
-    const double* sn = sums64 + n * C * 2;
+    for (int i = threadIdx.x; i < 2 * C; i += kT) {
+      double a = 0.0;
+      for (int r = 0; r < nrep; ++r) a += sums64[((int64_t)r * gridDim.y + n) * C * 2 + i];
+      ssum[i] = a;
+    }
+    __syncthreads();
+    const double* sn = ssum;
     int gprev = -1;
     float b = 0.f, c0 = 0.f, rstd = 0.f;
 #pragma unroll
@@ -457,7 +466,8 @@ __global__ void __launch_bounds__(kT) k_gn_bwd_apply(const bf16* __restrict__ g,
 // total = 16-byte pieces of ONE image
 inline int64_t apply_grid(int64_t total, int C8, int N) {
   int64_t grid = (total + kT - 1) / kT;
-  const int64_t cap = 256 * 16 / N > 64 ? 256 * 16 / N : 64;
+  static const int per_cu = [] { const char* e = getenv("MI_GN_BLOCKS_PER_CU"); return e && atoi(e) > 0 ? atoi(e) : 16; }();  // A/B knob
+  const int64_t cap = 256 * per_cu / N > 64 ? 256 * per_cu / N : 64;
   if (grid > cap) grid = cap;
   int m = C8;  // kT * grid % C8 == 0  <=>  grid % (C8 / gcd(C8, kT)) == 0
   for (int a = kT, b = C8; b;) { int t = a % b; a = b; b = t; m = C8 / a; }
@@ -468,7 +478,8 @@ inline int64_t apply_grid(int64_t total, int C8, int N) {
 
 inline int64_t pick_vchunk(int64_t V) {
   // ~1024 blocks whatever the volume: a 16^3 x 256-channel tensor cut into 2048-voxel chunks would be streamed by 2 CUs
-  int64_t vc = (V + 1023) / 1024;
+  static const int nchunks = [] { const char* e = getenv("MI_GN_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();  // A/B knob
+  int64_t vc = (V + nchunks - 1) / nchunks;
   if (vc < 16) vc = 16;
   return vc;
 }
@@ -542,7 +553,7 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   if (silu < 0 || silu > 2) return MI_ERR_BAD_ARG;
   auto kp = silu == 1 ? k_gn_bwd_partial<1> : (silu == 2 ? k_gn_bwd_partial<2> : k_gn_bwd_partial<0>);
   hipLaunchKernelGGL(kp, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride, (const bf16*)x,
-                     x_cstride, scale_shift, (float*)workspace, C, V, vc, gn_sweep() & 1, (double*)nullptr);
+                     x_cstride, scale_shift, (float*)workspace, C, V, vc, gn_sweep() & 1, (double*)nullptr, 1);
   hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(N * G), dim3(256), sizeof(float) * 2 * (size_t)(C / G), st, (const float*)workspace, chunks, C,
                      G, V, gamma, mean_rstd, coef, dgamma, dbeta);
   int64_t grid = apply_grid(V * (C / 8), C / 8, N);
@@ -558,7 +569,7 @@ int mi_gn_bwd(const void* g, int g_cstride, const void* x, int x_cstride, int N,
   else if (variant == 3) ka = silu == 1 ? k_gn_bwd_apply<1, 4, true> : (silu == 2 ? k_gn_bwd_apply<2, 4, true> : k_gn_bwd_apply<0, 4, true>);
   hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift, coef,
                      (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V, gn_sweep() & 1,
-                     (const double*)nullptr, (const float*)nullptr, (const float*)nullptr, G, (float*)nullptr, (float*)nullptr);
+                     (const double*)nullptr, (const float*)nullptr, (const float*)nullptr, G, (float*)nullptr, (float*)nullptr, 1);
   MI_CHECK_LAUNCH();
   return 0;
 }
@@ -573,18 +584,22 @@ int mi_gn_bwd_fused(const void* g, int g_cstride, const void* x, int x_cstride, 
   int chunks = (int)((V + vc - 1) / vc);
   int rows = kT / (C / 8);
   if (silu < 0 || silu > 2) return MI_ERR_BAD_ARG;
+  // replicas of the sums: one per 64 blocks of the partial pass, at most MI_GN_FUSED_REPLICAS (16; the caller's buffer is sized for that)
+  static const int rep_div = [] { const char* e = getenv("MI_GN_FUSED_REP_DIV"); return e && atoi(e) > 0 ? atoi(e) : 64; }();
+  int nrep = chunks / rep_div;
+  nrep = nrep < 1 ? 1 : (nrep > MI_GN_FUSED_REPLICAS ? MI_GN_FUSED_REPLICAS : nrep);
   auto kp = silu == 1 ? k_gn_bwd_partial<1> : (silu == 2 ? k_gn_bwd_partial<2> : k_gn_bwd_partial<0>);
   hipLaunchKernelGGL(kp, dim3(chunks, N), dim3(kT), sizeof(float) * (size_t)rows * C * 2, st, (const bf16*)g, g_cstride, (const bf16*)x,
-                     x_cstride, scale_shift, (float*)nullptr, C, V, vc, 0, sums_zeroed);
+                     x_cstride, scale_shift, (float*)nullptr, C, V, vc, 0, sums_zeroed, nrep);
   int64_t grid = apply_grid(V * (C / 8), C / 8, N);
   static const int variant = [] { const char* e = getenv("MI_GN_VARIANT"); return e ? atoi(e) : 2; }();
   auto ka = silu == 1 ? k_gn_bwd_apply<1, 2, false> : (silu == 2 ? k_gn_bwd_apply<2, 2, false> : k_gn_bwd_apply<0, 2, false>);
   if (variant == 1) ka = silu == 1 ? k_gn_bwd_apply<1, 4, false> : (silu == 2 ? k_gn_bwd_apply<2, 4, false> : k_gn_bwd_apply<0, 4, false>);
   else if (variant == 2) ka = silu == 1 ? k_gn_bwd_apply<1, 2, true> : (silu == 2 ? k_gn_bwd_apply<2, 2, true> : k_gn_bwd_apply<0, 2, true>);
   else if (variant == 3) ka = silu == 1 ? k_gn_bwd_apply<1, 4, true> : (silu == 2 ? k_gn_bwd_apply<2, 4, true> : k_gn_bwd_apply<0, 4, true>);
-  hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride, scale_shift,
-                     (const float*)nullptr, (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride, C / 8, V, 0,
-                     (const double*)sums_zeroed, gamma, mean_rstd, G, dgamma, dbeta);
+  hipLaunchKernelGGL(ka, dim3((int)grid, N), dim3(kT), sizeof(double) * 2 * (size_t)C, st, (const bf16*)g, g_cstride, (const bf16*)x, x_cstride,
+                     scale_shift, (const float*)nullptr, (const bf16*)add, add_cstride, (const bf16*)add2, add2_cstride, (bf16*)dx, dx_cstride,
+                     C / 8, V, 0, (const double*)sums_zeroed, gamma, mean_rstd, G, dgamma, dbeta, nrep);
   MI_CHECK_LAUNCH();
   return 0;
 }

@@ -251,9 +251,9 @@ class Ctx:
         fill per pass clears, so that no norm needs a zero-fill node of its own.  None when the fused form is off for this size."""
         if not (GN_BWD_FUSED or (voxels is not None and voxels <= GN_BWD_FUSED_MAXV)):
             return None
-        numel = (numel + 31) // 32 * 32
+        numel = (numel * ops.GN_FUSED_REPLICAS + 31) // 32 * 32  # (the kernel spreads its atomics over up to that many records)
         if self._z64 is None or self._z64_off + numel > self._z64.numel():
-            self._z64 = torch.zeros(max(1 << 17, numel), dtype=torch.float64, device=device)  # 1 MiB: ~130 norms of 256 channels x batch 2
+            self._z64 = torch.zeros(max(1 << 20, numel), dtype=torch.float64, device=device)  # 8 MiB: the ~50 norms of a C4 pass take 4
             self._z64_off = 0
         out = self._z64[self._z64_off:self._z64_off + numel]
         self._z64_off += numel

@@ -183,16 +183,19 @@ def gn_apply(x, st: GNStats, silu: bool):
     return y
 
 
+GN_FUSED_REPLICAS = 16  # MI_GN_FUSED_REPLICAS of include/medimgen_hip.h
+
+
 def gn_bwd(g, x, st: GNStats, gamma, silu: bool, dgamma, dbeta, add=None, add2=None, sums=None):
     """g = dL/d(act(GN(x))) -> dL/dx (+ add + add2: other pending branches of x's gradient, views allowed); dgamma/dbeta (fp32) are
-    accumulated in place.  sums: a ZEROED fp64 buffer of n * c * 2 elements (engine.Ctx.zeros64) selects the two-launch form
+    accumulated in place.  sums: a ZEROED fp64 buffer of GN_FUSED_REPLICAS * n * c * 2 elements (engine.Ctx.zeros64) selects the two-launch form
     (mi_gn_bwd_fused: atomics instead of the finalize launch)."""
     if add is None and add2 is not None:
         add, add2 = add2, None
     n, v, c = _vox(x)
     dx = torch.empty(x.shape, dtype=BF16, device=x.device)
     if sums is not None:
-        assert sums.dtype == torch.float64 and sums.numel() >= n * c * 2
+        assert sums.dtype == torch.float64 and sums.numel() >= GN_FUSED_REPLICAS * n * c * 2
         call("mi_gn_bwd_fused", ptr(g), _cs(g), ptr(x), _cs(x), n, v, c, st.groups, ptr(gamma), ptr(st.scale_shift), ptr(st.mean_rstd),
              int(silu), ptr(add), _cs(add) if add is not None else 0, ptr(add2), _cs(add2) if add2 is not None else 0, ptr(dx), c,
              ptr(dgamma), ptr(dbeta), ptr(sums))

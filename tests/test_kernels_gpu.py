@@ -108,7 +108,7 @@ def test_groupnorm_fwd_bwd(ops, shape, groups, silu):
     # the two-launch form (fp64 atomic sums, coefficients derived inside the apply pass): the same dx bit for bit up to the summation
     # order of the block totals, the same parameter gradients
     dgamma2, dbeta2 = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
-    sums = torch.zeros(2 * shape[0] * c, dtype=torch.float64, device=dev)
+    sums = torch.zeros(ops.GN_FUSED_REPLICAS * 2 * shape[0] * c, dtype=torch.float64, device=dev)  # replicated records of the atomic sums
     dx2 = ops.gn_bwd(cl(g), xc, st, gamma.to(dev), silu, dgamma2, dbeta2, add=cl(other), add2=cl(other2), sums=sums)
     check(cf(dx2), xr.grad + other + other2, 1.5e-2, "gn dx (fused)")
     assert float((dx2.float() - dx.float()).abs().max()) <= 2e-2 * float(dx.float().abs().max())
