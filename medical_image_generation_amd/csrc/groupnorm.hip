@@ -478,8 +478,10 @@ inline int64_t apply_grid(int64_t total, int C8, int N) {
 
 inline int64_t pick_vchunk(int64_t V) {
   // ~1024 blocks whatever the volume: a 16^3 x 256-channel tensor cut into 2048-voxel chunks would be streamed by 2 CUs
-  static const int nchunks = [] { const char* e = getenv("MI_GN_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 1024; }();  // A/B knob
-  int64_t vc = (V + nchunks - 1) / nchunks;
+  static const int nchunks = [] { const char* e = getenv("MI_GN_CHUNKS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();  // A/B knobs
+  static const int nchunks_big = [] { const char* e = getenv("MI_GN_CHUNKS_BIG"); return e && atoi(e) > 0 ? atoi(e) : 0; }();
+  const int nc = (nchunks_big && V >= (1 << 20)) ? nchunks_big : nchunks;
+  int64_t vc = (V + nc - 1) / nc;
   if (vc < 16) vc = 16;
   return vc;
 }
