@@ -1667,12 +1667,15 @@ struct PackSuper {
   int ng;
   int g[4];  // indices into the group table
 };
-constexpr int kPackSuperT = 1024;  // one block per CU (110 KB of LDS): 16 waves keep enough loads in flight
+constexpr int kPackSuperT = 1024;
+// The block is staged in LDS as bf16 (rounded on the way in: the same RNE conversion the fragments get, so the tables are bit for bit
+// what the fp32-staged version wrote): 55 KB instead of 110, so TWO blocks live on a CU and one's loads run under the other's stores
+// (one block per CU alternated a load phase and a store phase: 2.8 TB/s on the latent UNet's 441 M parameters).
 __global__ void __launch_bounds__(kPackSuperT) k_pack_super(const PackSuper* __restrict__ supers, const PackGroup* __restrict__ groups,
                                                     const int2* __restrict__ gtaps) {
-  extern __shared__ float sm[];
+  extern __shared__ unsigned short sm16[];
   const PackSuper su = supers[blockIdx.x];
-  const int run = 32 * su.KT, pitch = run + 1;
+  const int run = 32 * su.KT, pitch = run + 4;  // (a multiple of 4 halves: a float4 piece is stored as one aligned 8-byte write)
   const int nci = su.Ci_t - su.I0 < 32 ? su.Ci_t - su.I0 : 32, nvalid = nci * su.KT;
   const int nco = su.Co_t - su.O0 < 32 ? su.Co_t - su.O0 : 32;
   const int64_t row_stride = (int64_t)su.Ci_t * su.KT;
@@ -1691,8 +1694,8 @@ __global__ void __launch_bounds__(kPackSuperT) k_pack_super(const PackSuper* __r
       for (int u = 0; u < 5; ++u) {
         const int e = e0 + u * kPackSuperT, o = e / q, c4 = e - o * q;
         if (e < total) {
-          float* d = sm + o * pitch + 4 * c4;
-          d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+          u32x2 pk = {pack2(v[u][0], v[u][1]), pack2(v[u][2], v[u][3])};
+          *(u32x2*)(sm16 + o * pitch + 4 * c4) = pk;
         }
       }
     }
@@ -1708,7 +1711,7 @@ __global__ void __launch_bounds__(kPackSuperT) k_pack_super(const PackSuper* __r
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int e = e0 + u * kPackSuperT, o = e / nvalid, c = e - o * nvalid;
-        if (e < total) sm[o * pitch + c] = v[u];
+        if (e < total) sm16[o * pitch + c] = __builtin_bit_cast(unsigned short, (bf16)v[u]);
       }
     }
   }
@@ -1723,14 +1726,15 @@ __global__ void __launch_bounds__(kPackSuperT) k_pack_super(const PackSuper* __r
     const int crow = g.perm ? 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3) : rho;
     for (int ti = wave; ti < g.ntaps; ti += kPackSuperT / 64) {
       const int2 tf = gtaps[g.tap_off + ti];
-      F8 v;
+      unsigned hv[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = 8 * h + j;
         const int o = oo + (g.tr ? k : crow), i = io + (g.tr ? crow : k);
-        v.v[j] = (tf.x >= 0 && o < nco && i < nci) ? sm[o * pitch + i * su.KT + tf.x] : 0.f;
+        hv[j] = (tf.x >= 0 && o < nco && i < nci) ? (unsigned)sm16[o * pitch + i * su.KT + tf.x] : 0u;
       }
-      g.out[(int64_t)tf.y * 64 + lane] = pack8(v);
+      const u32x4 out = {hv[0] | (hv[1] << 16), hv[2] | (hv[3] << 16), hv[4] | (hv[5] << 16), hv[6] | (hv[7] << 16)};
+      g.out[(int64_t)tf.y * 64 + lane] = out;
     }
   }
 }
@@ -1805,44 +1809,61 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 // Few slabs, wide layers (256 -> 256: 1.8 M weights, 4 slabs): the element-per-thread kernel above spends its time in the scattered
 // read-modify-write of dw (one 4-byte element per 108-byte stride).  Here a block owns ONE output row of a (cout, cin) pair with all
 // its taps: the slab sums go through LDS and land in dw as one contiguous run of 32 * KT floats.
+// RR rows per block (round 3, late): with one row per block a 512 -> 512 layer launches 8192 blocks of ~3 loads per thread each -- the
+// launch is bound by block turnover and load latency (1.5 TB/s on the latent UNet's layers); RR rows share the block's fixed costs, put RR
+// independent loads in flight per thread and read RR * 128 contiguous bytes per (tap, split).
+template <int RR>
 __global__ void __launch_bounds__(256) k_wgrad_reduce_rows(const float* __restrict__ part, int64_t split_stride, int nsplit,
                                                            const int* __restrict__ uitems, const int* __restrict__ pair_off, int npairs,
                                                            float* __restrict__ dw, int Co_t, int Ci_t, int KT, CsReduce cs, int nmain) {
-  __shared__ float sm[32][33];   // [ci_l][tap]  (KT <= 32)
-  __shared__ unsigned present;   // taps this pair owns (strided convs split the taps over several pairs)
+  __shared__ float sm[RR][32][33];  // [row][ci_l][tap]  (KT <= 32)
+  __shared__ unsigned present;      // taps this pair owns (strided convs split the taps over several pairs)
   if ((int)blockIdx.x >= nmain) { cs_reduce_block(cs, blockIdx.x - nmain); return; }  // whole block: the column-sum fold
-  const int pair = blockIdx.x >> 5, co_l = blockIdx.x & 31;
+  constexpr int GPP = 32 / RR;  // row groups per pair
+  const int pair = blockIdx.x / GPP, co_l0 = (blockIdx.x % GPP) * RR;
   const int off = pair_off[pair];
   const int nt = (int)(((pair + 1 < npairs ? (int64_t)pair_off[pair + 1] : split_stride) - off) >> 10);
   const int* it0 = uitems + (off >> 10) * 4;
-  const int co = it0[1] + co_l, ci0 = it0[2];
-  if (co >= Co_t) return;  // whole block
+  const int co0 = it0[1] + co_l0, ci0 = it0[2];
+  if (co0 >= Co_t) return;  // whole block
   if (threadIdx.x == 0) present = 0u;
   __syncthreads();
   const int ci_l = threadIdx.x & 31;
   for (int t = threadIdx.x >> 5; t < nt; t += 8) {
     const int tap = it0[t * 4];
     if (tap < 0) continue;
-    const float* p = part + off + t * 1024 + co_l * 32 + ci_l;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const float* p = part + off + t * 1024 + co_l0 * 32 + ci_l;
+    float s[RR][4];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) s[r][0] = s[r][1] = s[r][2] = s[r][3] = 0.f;
     int k = 0;
-    for (; k + 3 < nsplit; k += 4) {
-      s0 += p[(int64_t)k * split_stride];
-      s1 += p[(int64_t)(k + 1) * split_stride];
-      s2 += p[(int64_t)(k + 2) * split_stride];
-      s3 += p[(int64_t)(k + 3) * split_stride];
+    for (; k + 3 < nsplit; k += 4) {  // (four running sums per row, folded pairwise: the order the one-row kernel used)
+#pragma unroll
+      for (int r = 0; r < RR; ++r) {
+        s[r][0] += p[(int64_t)k * split_stride + r * 32];
+        s[r][1] += p[(int64_t)(k + 1) * split_stride + r * 32];
+        s[r][2] += p[(int64_t)(k + 2) * split_stride + r * 32];
+        s[r][3] += p[(int64_t)(k + 3) * split_stride + r * 32];
+      }
     }
-    for (; k < nsplit; ++k) s0 += p[(int64_t)k * split_stride];
-    sm[ci_l][tap] = (s0 + s1) + (s2 + s3);
+    for (; k < nsplit; ++k)
+#pragma unroll
+      for (int r = 0; r < RR; ++r) s[r][0] += p[(int64_t)k * split_stride + r * 32];
+#pragma unroll
+    for (int r = 0; r < RR; ++r) sm[r][ci_l][tap] = (s[r][0] + s[r][1]) + (s[r][2] + s[r][3]);
     if (ci_l == 0) atomicOr(&present, 1u << tap);
   }
   __syncthreads();
   const unsigned mask = present;
   const int nci = Ci_t - ci0 < 32 ? Ci_t - ci0 : 32;
-  float* row = dw + ((int64_t)co * Ci_t + ci0) * KT;
-  for (int e = threadIdx.x; e < nci * KT; e += 256) {
-    const int c = e / KT, tap = e - c * KT;
-    if (mask >> tap & 1u) row[e] += sm[c][tap];
+#pragma unroll
+  for (int r = 0; r < RR; ++r) {
+    if (co0 + r >= Co_t) break;
+    float* row = dw + ((int64_t)(co0 + r) * Ci_t + ci0) * KT;
+    for (int e = threadIdx.x; e < nci * KT; e += 256) {
+      const int c = e / KT, tap = e - c * KT;
+      if (mask >> tap & 1u) row[e] += sm[r][c][tap];
+    }
   }
 }
 
@@ -1912,9 +1933,17 @@ inline void launch_wgrad_reduce(const float* part, int64_t split_stride, int nsp
   if (nsplit >= 32)
     hipLaunchKernelGGL(k_wgrad_reduce<8>, dim3(nitems * 32 + extra), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT,
                        cs, nitems * 32);
-  else if (rows_kernel && KT <= 32 && npairs >= 8)
-    hipLaunchKernelGGL(k_wgrad_reduce_rows, dim3(npairs * 32 + extra), dim3(256), 0, st, part, split_stride, nsplit, uitems, pair_off, npairs, dw,
-                       Co_t, Ci_t, KT, cs, npairs * 32);
+  else if (rows_kernel && KT <= 32 && npairs >= 8) {
+    // rows of a (cout block, cin chunk) pair per block.  Same-box (profiles/r04a_ab_reduce_rr*.log): the latent UNet (256-576 pairs per layer:
+    // 8-18 k one-row blocks) 56.25 ms with 1, 55.85 with 2, 55.74 with 4, 56.17 with 8; the C4 net (16-64 pairs) 21.37 with 1, 21.49 with 4:
+    // few pairs need every block they can get.  MI_WGRAD_REDUCE_RR overrides.
+    static const int rr_env = env_int("MI_WGRAD_REDUCE_RR", 0);
+    const int rr = rr_env > 0 ? rr_env : (npairs >= 128 ? 4 : 1);
+    auto kr = rr >= 8 ? k_wgrad_reduce_rows<8> : rr >= 4 ? k_wgrad_reduce_rows<4> : rr >= 2 ? k_wgrad_reduce_rows<2> : k_wgrad_reduce_rows<1>;
+    const int gpp = 32 / (rr >= 8 ? 8 : rr >= 4 ? 4 : rr >= 2 ? 2 : 1);
+    hipLaunchKernelGGL(kr, dim3(npairs * gpp + extra), dim3(256), 0, st, part, split_stride, nsplit, uitems, pair_off, npairs, dw, Co_t, Ci_t, KT,
+                       cs, npairs * gpp);
+  }
   else if (nsplit >= 8)
     hipLaunchKernelGGL(k_wgrad_reduce<4>, dim3(nitems * 16 + extra), dim3(256), 0, st, part, split_stride, nsplit, uitems, nitems, dw, Co_t, Ci_t, KT,
                        cs, nitems * 16);
@@ -2693,7 +2722,7 @@ int mi_conv_pack_batch_create(mi_pack_batch** out, mi_conv_plan* const* plans, c
         if (su.ng < 4) su.g[su.ng++] = (int)gi;
         else super_ok = false;  // (more than four groups in one block: not a layout this file produces)
       }
-      const size_t need_su = sizeof(float) * 32 * (size_t)(32 * P->KT + 1);
+      const size_t need_su = sizeof(unsigned short) * 32 * (size_t)(32 * P->KT + 4);  // (bf16 staging: k_pack_super)
       if (need_su > lds_super) lds_super = need_su;
     }
     const size_t need = sizeof(float) * 32 * (size_t)(16 * P->KT + 1) > sizeof(float) * 16 * (size_t)(32 * P->KT + 1)

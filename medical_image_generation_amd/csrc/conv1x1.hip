@@ -341,8 +341,13 @@ int launch_w11(const W11Args& p, int gy, int gz, hipStream_t st) {
     attr_set = true;
   }
   const int64_t ntiles = (p.nvox + 255) / 256;
-  int gx = 512 / (gy * gz);
-  if (gx < 32) gx = 32;
+  // splits over the voxel tiles: every split ends in (NCO * NCI * 1024) float atomics per workgroup, so wide layers (many channel pairs)
+  // want few of them.  MI_W11_MIN_SPLIT / MI_W11_WGS: A/B knobs
+  // (32 / 512 until late in round 3; 4: C3b 58.0 -> 57.2 ms, C5 48.3 -> 47.5, C4 21.51 -> 21.44, profiles/r04a_ab_w11_split*.log)
+  static const int min_split = [] { const char* e = getenv("MI_W11_MIN_SPLIT"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
+  static const int want_wgs = [] { const char* e = getenv("MI_W11_WGS"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
+  int gx = want_wgs / (gy * gz);
+  if (gx < min_split) gx = min_split;
   if (gx > ntiles) gx = (int)ntiles;
   hipLaunchKernelGGL(kern, dim3(gx, gy, gz), dim3(512), lds, st, p);
   MI_CHECK_LAUNCH();
