@@ -58,6 +58,13 @@ int mi_gn_stats(const void* x, int x_cstride, int N, int64_t V, int C, int G, fl
 int mi_gn_stats_from_partial(const float* partial_a, int chunks_a, int Ca, const float* partial_b, int chunks_b, int Cb, int N, int64_t V,
                              int G, float eps, const float* gamma, const float* beta, float* scale_shift, float* mean_rstd,
                              hipStream_t stream);
+/* Small tensors (N * G workgroups hold the whole tensor in registers: C / G in {8, 16} channels per group, V * (C / G) / 8 <= 8192 --
+ * the 16^3 level of a 3-D net, 2-D nets): statistics, coefficients and act(GN(x)) in ONE launch instead of three at launch floor.
+ * Writes the same scale_shift / mean_rstd records mi_gn_stats does (the backward reads them).  act: 0 none, 1 SiLU, 2 LeakyReLU(0.2).
+ * MI_ERR_UNSUPPORTED outside that range (mi_gn_small_supported tells without launching). */
+int mi_gn_small_supported(int N, int64_t V, int C, int G);
+int mi_gn_small_fwd(const void* x, int x_cstride, void* y, int y_cstride, int N, int64_t V, int C, int G, float eps, const float* gamma,
+                    const float* beta, float* scale_shift, float* mean_rstd, int act, hipStream_t stream);
 /* y = (silu?)(x*scale+shift) */
 int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y, int y_cstride, int N, int64_t V, int C, int silu,
                 hipStream_t stream);

@@ -74,6 +74,8 @@ _SIGS = {
     "mi_avgpool_fwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_avgpool_bwd": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p],
     "mi_crop_pad": [_p, _i, _i, _i, _i, _i, _p, _p, _i, _i, _i, _f, _i, _f, _i, _p],
+    "mi_gn_small_supported": [_i, _l, _i, _i],
+    "mi_gn_small_fwd": [_p, _i, _p, _i, _i, _l, _i, _i, _f, _p, _p, _p, _p, _i, _p],
     "mi_aug_stats_workspace_bytes": [],
     "mi_aug_plane_stats": [_p, _l, _p, _p, _p],
     "mi_aug_pointwise": [_p, _l, _i, _f, _p, _p, _p, _p],
@@ -101,7 +103,7 @@ _SIGS = {
     "mi_scale_f32": [_p, _f, _l, _p],
 }
 _RET = {"mi_gn_workspace_bytes": _l, "mi_attn_workspace_bytes": _l, "mi_aug_stats_workspace_bytes": _l}
-_NOCHECK = {"mi_abi_version", "mi_gn_workspace_bytes", "mi_aug_stats_workspace_bytes", "mi_attn_supported", "mi_attn_workspace_bytes", "mi_conv_fwd_stats_chunks"}
+_NOCHECK = {"mi_abi_version", "mi_gn_small_supported", "mi_gn_workspace_bytes", "mi_aug_stats_workspace_bytes", "mi_attn_supported", "mi_attn_workspace_bytes", "mi_conv_fwd_stats_chunks"}
 
 _lib = None
 # Version of the C ABI this binding was written against (csrc/api.hip: mi_abi_version).  Entry points have changed their argument

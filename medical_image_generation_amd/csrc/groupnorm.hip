@@ -496,6 +496,103 @@ inline int gn_sweep() {
 }
 inline bool bad_c(int C, int G) { return C <= 0 || (C & 7) || C > 2048 || G <= 0 || C % G != 0; }
 
+// ---- small tensors (the 16^3 level of the C4 net; 2-D nets): statistics -> coefficients -> apply in ONE launch.  Three launches of
+// ~6 us each (launch floor: the tensors are 2 MB) plus their boundaries cost ~22 us per norm and there are ~20 such norms per pass.
+// One 1024-thread workgroup per (image, group): a group's channels are an aligned run of 16 or 32 bytes per voxel, every thread issues
+// ALL its loads up front (<= 8 pieces of 16 bytes; the group's 64-128 KB stay in registers), one block-wide fp64 fold gives mean / rstd,
+// and the activated tensor is written from the registers.  (Round 2 tried one 256-thread block per group looping over the voxels:
+// a chain of load latencies, slower than the three launches.)
+constexpr int kSmallT = 1024, kSmallP = 8;
+__device__ __forceinline__ void block_sum2_d16(double& a, double& b, double* red) {  // 16 waves
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+    red[(threadIdx.x >> 6) * 2] = a;
+    red[(threadIdx.x >> 6) * 2 + 1] = b;
+  }
+  __syncthreads();
+  a = b = 0.0;
+#pragma unroll
+  for (int w = 0; w < kSmallT / 64; ++w) {
+    a += red[2 * w];
+    b += red[2 * w + 1];
+  }
+}
+template <int ACT>
+__global__ void __launch_bounds__(kSmallT) k_gn_small_fwd(const bf16* __restrict__ x, int xcs, bf16* __restrict__ y, int ycs, int C, int G, int V,
+                                                          float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ scale_shift, float* __restrict__ mean_rstd) {
+  __shared__ double red[2 * kSmallT / 64];
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int cpg = C / G, pcs = cpg >> 3;            // 16-byte pieces per voxel of this group (1 or 2)
+  const int total = V * pcs;                        // <= kSmallP * kSmallT
+  const int q = threadIdx.x % pcs;                  // this thread's octet inside the group: the same for all its pieces (1024 % pcs == 0)
+  const bf16* xb = x + (int64_t)n * V * xcs + g * cpg + q * 8;
+  u32x4 raw[kSmallP];
+#pragma unroll
+  for (int i = 0; i < kSmallP; ++i) {
+    const int idx = threadIdx.x + i * kSmallT;
+    u32x4 z = {0u, 0u, 0u, 0u};
+    raw[i] = idx < total ? *(const u32x4*)(xb + (int64_t)(idx / pcs) * xcs) : z;
+  }
+  float s = 0.f, sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < kSmallP; ++i) {
+    const F8 f = unpack8(raw[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s += f.v[j];
+      sq = fmaf(f.v[j], f.v[j], sq);
+    }
+  }
+  double ds = (double)s, dq = (double)sq;
+  block_sum2_d16(ds, dq, red);
+  const double m = (double)V * cpg;
+  const double mean = ds / m;
+  double var = dq / m - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  float sc[8], sh[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = g * cpg + q * 8 + j;
+    sc[j] = gamma[c] * rstd;
+    sh[j] = beta[c] - (float)mean * sc[j];
+  }
+  if (threadIdx.x < pcs) {  // one thread per octet publishes what the backward (and any other consumer of the statistics) reads
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = g * cpg + q * 8 + j;
+      scale_shift[((int64_t)n * C + c) * 2] = sc[j];
+      scale_shift[((int64_t)n * C + c) * 2 + 1] = sh[j];
+    }
+    if (threadIdx.x == 0) {
+      mean_rstd[((int64_t)n * G + g) * 2] = (float)mean;
+      mean_rstd[((int64_t)n * G + g) * 2 + 1] = rstd;
+    }
+  }
+  bf16* yb = y + (int64_t)n * V * ycs + g * cpg + q * 8;
+#pragma unroll
+  for (int i = 0; i < kSmallP; ++i) {
+    const int idx = threadIdx.x + i * kSmallT;
+    if (idx < total) {
+      F8 f = unpack8(raw[i]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f.v[j] = act_f<ACT>(f.v[j] * sc[j] + sh[j]);
+      *(u32x4*)(yb + (int64_t)(idx / pcs) * ycs) = pack8(f);
+    }
+  }
+}
+inline bool small_ok(int N, int64_t V, int C, int G) {
+  if (bad_c(C, G) || N <= 0 || V <= 0) return false;
+  const int cpg = C / G;
+  return (cpg == 8 || cpg == 16) && V * (cpg >> 3) <= (int64_t)kSmallP * kSmallT;
+}
+
 }  // namespace
 
 extern "C" {
@@ -538,6 +635,21 @@ int mi_gn_apply(const void* x, int x_cstride, const float* scale_shift, void* y,
   auto k = silu == 1 ? k_gn_apply<1> : (silu == 2 ? k_gn_apply<2> : k_gn_apply<0>);
   hipLaunchKernelGGL(k, dim3((int)grid, N), dim3(kT), 0, st, (const bf16*)x, x_cstride, scale_shift, (bf16*)y, y_cstride, C / 8, V,
                      gn_sweep() & 2 ? 1 : 0);
+  MI_CHECK_LAUNCH();
+  return 0;
+}
+
+int mi_gn_small_supported(int N, int64_t V, int C, int G) { return small_ok(N, V, C, G) ? 1 : 0; }
+
+int mi_gn_small_fwd(const void* x, int x_cstride, void* y, int y_cstride, int N, int64_t V, int C, int G, float eps, const float* gamma,
+                    const float* beta, float* scale_shift, float* mean_rstd, int act, hipStream_t st) {
+  if (!small_ok(N, V, C, G)) return MI_ERR_UNSUPPORTED;
+  if (!x || !y || !gamma || !beta || !scale_shift || !mean_rstd || (x_cstride & 7) || (y_cstride & 7) || x_cstride < C || y_cstride < C ||
+      act < 0 || act > 2)
+    return MI_ERR_BAD_ARG;
+  auto k = act == 1 ? k_gn_small_fwd<1> : (act == 2 ? k_gn_small_fwd<2> : k_gn_small_fwd<0>);
+  hipLaunchKernelGGL(k, dim3(G, N), dim3(kSmallT), 0, st, (const bf16*)x, x_cstride, (bf16*)y, y_cstride, C, G, (int)V, eps, gamma, beta,
+                     scale_shift, mean_rstd);
   MI_CHECK_LAUNCH();
   return 0;
 }

@@ -7,6 +7,7 @@ allocator, hipGraph-friendly); nothing here computes with torch ops.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -140,14 +141,42 @@ def _workspace(nbytes, device):
 
 
 class GNStats:
-    __slots__ = ("scale_shift", "mean_rstd", "groups", "name")
+    """Per-(n, channel) scale / shift and per-(n, group) mean / rstd of one GroupNorm.  `pending`: the statistics of a SMALL tensor are
+    not computed yet -- gn_apply() will produce them together with the activated tensor in one launch (mi_gn_small_fwd); any other
+    reader of the records gets them from the plain statistics pass first."""
+    __slots__ = ("_ss", "_mr", "groups", "name", "_pending")
 
-    def __init__(self, scale_shift, mean_rstd, groups):
-        self.scale_shift, self.mean_rstd, self.groups = scale_shift, mean_rstd, groups
+    def __init__(self, scale_shift, mean_rstd, groups, pending=None):
+        self._ss, self._mr, self.groups, self._pending = scale_shift, mean_rstd, groups, pending
+
+    def _force(self):
+        if self._pending is not None:
+            x, eps, gamma, beta = self._pending
+            self._pending = None
+            st = gn_stats(x, self.groups, eps, gamma, beta, allow_small=False)
+            self._ss, self._mr = st._ss, st._mr
+
+    @property
+    def scale_shift(self):
+        self._force()
+        return self._ss
+
+    @property
+    def mean_rstd(self):
+        self._force()
+        return self._mr
 
 
-def gn_stats(x, groups, eps, gamma, beta) -> GNStats:
+# A/B knob, default OFF: single-launch GroupNorm (statistics + coefficients + apply) for tensors a workgroup per group can hold.  Measured
+# (round 3, profiles/r03gs_ab_gn_small_fwd.log): 21.34 ms/step either way -- the launch takes 16.8 us (32 workgroups pulling 16-byte
+# pieces at a 512-byte stride through 32 of the 256 CUs) where the three chip-wide launches it replaces take ~18 us with their boundaries.
+GN_SMALL = os.environ.get("MI_GN_SMALL", "0") == "1"
+
+
+def gn_stats(x, groups, eps, gamma, beta, allow_small=True) -> GNStats:
     n, v, c = _vox(x)
+    if allow_small and GN_SMALL and c % groups == 0 and _lib.call_raw("mi_gn_small_supported", n, v, c, groups):
+        return GNStats(None, None, groups, pending=(x, float(eps), gamma, beta))
     ss = torch.empty((n, c, 2), dtype=F32, device=x.device)
     mr = torch.empty((n, groups, 2), dtype=F32, device=x.device)
     nb = _lib.call_raw("mi_gn_workspace_bytes", n, v, c)
@@ -179,6 +208,13 @@ def gn_stats_from_sums(a: ChannelSums, b: ChannelSums | None, n, v, groups, eps,
 def gn_apply(x, st: GNStats, silu: bool):
     n, v, c = _vox(x)
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    if st._pending is not None and st._pending[0] is x:
+        _, eps, gamma, beta = st._pending
+        st._pending = None
+        st._ss = torch.empty((n, c, 2), dtype=F32, device=x.device)
+        st._mr = torch.empty((n, st.groups, 2), dtype=F32, device=x.device)
+        call("mi_gn_small_fwd", ptr(x), _cs(x), ptr(y), c, n, v, c, st.groups, eps, ptr(gamma), ptr(beta), ptr(st._ss), ptr(st._mr), int(silu))
+        return y
     call("mi_gn_apply", ptr(x), _cs(x), ptr(st.scale_shift), ptr(y), c, n, v, c, int(silu))
     return y
 

@@ -78,6 +78,36 @@ def test_elementwise_family(ops):
     check(ops.colsum(cl(x1)).cpu(), x1.sum(dim=(2, 3, 4)), 1e-3, "colsum ragged")
 
 
+@pytest.mark.parametrize("shape,groups", [((1, 256, 16, 16, 16), 32), ((2, 512, 16, 16, 16), 32), ((2, 256, 5, 6, 7), 32), ((3, 128, 1, 40, 40), 16),
+                                          ((1, 512, 4, 4, 4), 32)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_single_launch_groupnorm_equals_three_launches(ops, shape, groups, act, monkeypatch):
+    """Small tensors can take statistics -> coefficients -> apply in ONE launch (mi_gn_small_fwd inside gn_apply, MI_GN_SMALL=1); the records
+    it leaves for the backward and the activated tensor must be those of the three-launch path up to the summation order of the
+    statistics (fp32 partials, fp64 finish in both)."""
+    monkeypatch.setattr(ops, "GN_SMALL", True)
+    n, c = shape[0], shape[1]
+    v = shape[2] * shape[3] * shape[4]
+    assert ops._lib.call_raw("mi_gn_small_supported", n, v, c, groups) == 1
+    assert ops._lib.call_raw("mi_gn_small_supported", 1, 32 ** 3, 128, 32) == 0 and ops._lib.call_raw("mi_gn_small_supported", 1, 4096, 384, 32) == 0
+    x = (rnd(*shape, scale=1.5) + 0.3).bfloat16().float()
+    gamma, beta = (1 + 0.2 * rnd(c, seed=5)).to(dev), (0.1 * rnd(c, seed=6)).to(dev)
+    xc = cl(x)
+    st1 = ops.gn_stats(xc, groups, 1e-6, gamma, beta)
+    assert st1._pending is not None
+    y1 = ops.gn_apply(xc, st1, act)
+    assert st1._pending is None
+    st3 = ops.gn_stats(xc, groups, 1e-6, gamma, beta, allow_small=False)
+    y3 = ops.gn_apply(xc, st3, act)
+    assert torch.allclose(st1.mean_rstd, st3.mean_rstd, rtol=2e-6, atol=1e-7)
+    assert torch.allclose(st1.scale_shift, st3.scale_shift, rtol=2e-6, atol=1e-6)
+    assert float((y1 != y3).float().mean()) <= 2e-3, "more than rounding flips between the two forms"
+    assert float((y1.float() - y3.float()).abs().max()) <= 2e-2 * float(y3.float().abs().max())
+    # a reader of the records before any apply gets them from the plain statistics pass
+    st2 = ops.gn_stats(xc, groups, 1e-6, gamma, beta)
+    assert torch.equal(st2.scale_shift, st3.scale_shift) and st2._pending is None
+
+
 @pytest.mark.parametrize("shape,groups", [((2, 32, 4, 6, 5), 32), ((1, 96, 8, 8, 8), 32), ((2, 64, 1, 16, 16), 16),
                                           ((1, 16, 5, 5, 5), 8), ((1, 512, 4, 4, 4), 32),
                                           # coarse-level shapes (8 / 16 channels per group, few voxels)
