@@ -16,6 +16,19 @@ import os
 import torch
 
 
+def _load(path):
+    """torch.load(weights_only=True) with numpy scalars admitted: the reference's trainers store `validation_loss` as whatever their
+    validation loop returned, which is a numpy float when it came out of np.mean (tensors, numbers, containers and these only)."""
+    import numpy as np
+    allow = [np.dtype, np.float64, np.float32, np.int64] + [type(np.dtype(t)) for t in (np.float64, np.float32, np.int64)]
+    try:
+        allow.append(np._core.multiarray.scalar)
+    except AttributeError:  # numpy < 2
+        allow.append(np.core.multiarray.scalar)
+    with torch.serialization.safe_globals(allow):
+        return torch.load(path, map_location="cpu", weights_only=True)
+
+
 def optimizer_state_dict(trainer) -> dict:
     """torch.optim.Adam / AdamW state of the trainer's fused optimizer (CPU tensors, like a torch checkpoint after map_location='cpu')."""
     a, model = trainer.arena, trainer.model
@@ -73,7 +86,7 @@ def save_model(trainer, results_path, epoch, validation_loss, scheduler=None) ->
     torch.save(checkpoint, last)
     best = os.path.join(save_path, "best_model.pth")
     if os.path.isfile(best):
-        best_loss = torch.load(best, map_location="cpu", weights_only=True).get("validation_loss", float("inf"))
+        best_loss = _load(best).get("validation_loss", float("inf"))
         if validation_loss < best_loss:
             torch.save(checkpoint, best)
     else:
@@ -83,7 +96,7 @@ def save_model(trainer, results_path, epoch, validation_loss, scheduler=None) ->
 
 def load_model(trainer, load_model_path, load_optimizer=True, lr_scheduler=None, for_training=False):
     """train_ldm.py:492-505.  Returns the epoch to resume at when for_training."""
-    checkpoint = torch.load(load_model_path, map_location="cpu", weights_only=True)
+    checkpoint = _load(load_model_path)
     trainer.model.load_state_dict(checkpoint["network_state_dict"])
     if load_optimizer:
         load_optimizer_state_dict(trainer, checkpoint["optimizer_state_dict"])

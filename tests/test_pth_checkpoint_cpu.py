@@ -41,3 +41,13 @@ def test_optimizer_state_dict_is_torch_adamw_layout():
             covered[o:o + math.prod(t.arena.shapes[name])] = True
     assert torch.equal(t.exp_avg[covered], want[covered]) and float(t.step_count) == 3.0
     assert ck.optimizer_state_dict(_FakeTrainer(net, 0))["state"] == {}
+
+
+def test_checkpoint_with_numpy_validation_loss_loads(tmp_path):
+    """The reference writes `validation_loss` as its validation loop returned it: a numpy float after np.mean.  The safe loader takes it."""
+    import numpy as np
+    from medical_image_generation_amd import checkpoint as ck
+    path = tmp_path / "best_model.pth"
+    torch.save({"epoch": 3, "validation_loss": np.float64(0.25), "network_state_dict": {"w": torch.ones(2)}}, path)
+    got = ck._load(str(path))
+    assert got["epoch"] == 3 and float(got["validation_loss"]) == 0.25 and torch.equal(got["network_state_dict"]["w"], torch.ones(2))
