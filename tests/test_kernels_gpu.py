@@ -488,3 +488,20 @@ def test_adam_matches_torch(ops, decoupled, wd):
         call("mi_adam_step", ptr(p), ptr(gd4), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, wd, decoupled, ptr(sumsq), 1.0, 0.25, ptr(step))
     assert float(step) == 3.0
     check(p.cpu(), pr.detach(), 1e-5, "adam params")
+
+
+@pytest.mark.parametrize("rows,fin,fout", [(4096, 256, 768), (16384, 512, 1536), (1000, 768, 2304), (27, 64, 192), (4096, 96, 32), (515, 32, 32)])
+def test_linear_weight_gradient_matches_fp32(rows, fin, fout):
+    """mi_linear_wgrad_bf16 (the q/k/v Linear of AttentionBlock, UNet:379-381, and every 1x1 conv's weight gradient): dW += dy^T x,
+    db += column sums of dy, on bf16 operands with fp32 accumulation -- over few or many voxel splits (the launch picks 4-32 of them;
+    both ends of that range are hit by these shapes), ragged row counts and channel counts that are not multiples of 64."""
+    from medical_image_generation_amd._lib import call, ptr
+    x, dy = rnd(rows, fin, seed=1), rnd(rows, fout, seed=2)
+    dw0, db0 = rnd(fout, fin, seed=3), rnd(fout, seed=4)
+    dw, db = dw0.to(dev).contiguous(), db0.to(dev).contiguous()
+    call("mi_linear_wgrad_bf16", ptr(x.to(dev).bfloat16().contiguous()), fin, fin, ptr(dy.to(dev).bfloat16().contiguous()), fout, fout, rows,
+         ptr(dw), ptr(db))
+    want_w = dw0.double() + dy.double().t() @ x.double()
+    want_b = db0.double() + dy.double().sum(0)
+    check(dw.cpu().double(), want_w, 2e-3, "linear dW")
+    check(db.cpu().double(), want_b, 2e-3, "linear db")
