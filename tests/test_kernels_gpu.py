@@ -499,8 +499,9 @@ def test_linear_weight_gradient_matches_fp32(rows, fin, fout):
     x, dy = rnd(rows, fin, seed=1), rnd(rows, fout, seed=2)
     dw0, db0 = rnd(fout, fin, seed=3), rnd(fout, seed=4)
     dw, db = dw0.to(dev).contiguous(), db0.to(dev).contiguous()
-    call("mi_linear_wgrad_bf16", ptr(x.to(dev).bfloat16().contiguous()), fin, fin, ptr(dy.to(dev).bfloat16().contiguous()), fout, fout, rows,
-         ptr(dw), ptr(db))
+    xb, dyb = x.to(dev).bfloat16().contiguous(), dy.to(dev).bfloat16().contiguous()  # (held: a temporary's block would be reused by the next one)
+    call("mi_linear_wgrad_bf16", ptr(xb), fin, fin, ptr(dyb), fout, fout, rows, ptr(dw), ptr(db))
+    torch.cuda.synchronize()
     want_w = dw0.double() + dy.double().t() @ x.double()
     want_b = db0.double() + dy.double().sum(0)
     check(dw.cpu().double(), want_w, 2e-3, "linear dW")
