@@ -330,6 +330,97 @@ __global__ void __launch_bounds__(512, 2) k_wgrad1x1(W11Args p) {
     }
 }
 
+// Wide layers (the latent UNet's q/k/v Linear: 512 -> 1536 over 16 k tokens).  k_wgrad1x1's eight waves all hold the workgroup's whole
+// 64 x 64 block and split the voxels, so a launch re-reads its operands (Cout / 64 + Cin / 64) / 2 times from the Infinity Cache: 805 MB,
+// 32 flop per byte, ~75 us.  Here the waves own SUB-BLOCKS of a 128 x 128 workgroup block (wave -> two cout blocks x one cin block,
+// every wave walks all 16 k-steps of a tile): half the re-reads, no fold across waves in the epilogue.  Cin, Cout multiples of 128.
+__global__ void __launch_bounds__(512, 1) k_wgrad1x1_wide(W11Args p) {
+  constexpr int IMG = 256 * 64, NB = 4;  // 32-channel chunk image of a tile; 4 x-chunks + 4 dy-chunks = 128 KB
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ci_base = blockIdx.y * 128, co_base = blockIdx.z * 128;
+  typedef __attribute__((address_space(3))) char lds_char;
+  const unsigned l0 = (unsigned)(size_t)(lds_char*)lds;
+  const int64_t ntiles = (p.nvox + 255) >> 8;
+  constexpr int PP = NB * 1024 / 512;  // 16-byte pieces per thread and operand
+  u32x4 xr[PP], yr[PP];
+  auto load_tile = [&](int64_t t) {
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+      const int pc = threadIdx.x + 512 * i;  // voxel-major over the 16 pieces of a voxel
+      const int v = pc >> 4, q = pc & 15;
+      const int64_t gv = t * 256 + v;
+      u32x4 z = {0u, 0u, 0u, 0u};
+      xr[i] = gv < p.nvox ? *(const u32x4*)(p.x + gv * p.x_cs + ci_base + q * 8) : z;
+      yr[i] = gv < p.nvox ? *(const u32x4*)(p.dy + gv * p.dy_cs + co_base + q * 8) : z;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < PP; ++i) {
+      const int pc = threadIdx.x + 512 * i;
+      const int v = pc >> 4, q = pc & 15;
+      *(u32x4*)(lds + (q >> 2) * IMG + v * 64 + (q & 3) * 16) = xr[i];
+      *(u32x4*)(lds + (NB + (q >> 2)) * IMG + v * 64 + (q & 3) * 16) = yr[i];
+    }
+  };
+  const int wo = wave >> 2, wc = wave & 3;  // cout blocks {2 wo, 2 wo + 1}, cin block wc
+  f32x16 acc[2], cs[2];
+#pragma unroll
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[o][e] = cs[o][e] = 0.f;
+  const bool do_cs = p.colsum != nullptr && blockIdx.y == 0 && wc == 0;  // (one column of waves sees every voxel of its cout blocks)
+  const int gq = lane >> 4, qv = (lane >> 2) & 3, pp = lane & 3;
+  const unsigned lane_off = ((gq >> 1) * 8 + qv) * 64 + ((gq & 1) * 16 + pp * 4) * 2;
+  int64_t t = blockIdx.x;
+  if (t < ntiles) load_tile(t);
+  for (; t < ntiles; t += gridDim.x) {
+    __syncthreads();  // previous tile consumed
+    store_tile();
+    __syncthreads();
+    if (t + gridDim.x < ntiles) load_tile(t + gridDim.x);  // in flight under the MFMAs
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const unsigned koff = (unsigned)(ks * 16 * 64) + lane_off;
+      u32x2 fa[2][2], fb[2];
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        tr_read8(fa[o][0], l0 + (NB + 2 * wo + o) * IMG + koff);
+        tr_read8(fa[o][1], l0 + (NB + 2 * wo + o) * IMG + koff + 4 * 64);
+      }
+      tr_read8(fb[0], l0 + wc * IMG + koff);
+      tr_read8(fb[1], l0 + wc * IMG + koff + 4 * 64);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int o = 0; o < 2; ++o) asm volatile("" : "+v"(fa[o][0]), "+v"(fa[o][1]));
+      asm volatile("" : "+v"(fb[0]), "+v"(fb[1]));
+      __builtin_amdgcn_sched_barrier(0);
+      const u32x4 rb = {fb[0][0], fb[0][1], fb[1][0], fb[1][1]};
+#pragma unroll
+      for (int o = 0; o < 2; ++o) {
+        const u32x4 ra = {fa[o][0][0], fa[o][0][1], fa[o][1][0], fa[o][1][1]};
+        acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra), __builtin_bit_cast(bf16x8, rb), acc[o], 0, 0, 0);
+        if (do_cs) {
+          const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
+          cs[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ra), __builtin_bit_cast(bf16x8, ones), cs[o], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D map: col = lane & 31 -> ci, row (e & 3) + 8 (e >> 2) + 4 (lane >> 5) -> co
+  const int hh = lane >> 5;
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co_base + (2 * wo + o) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh, ci = ci_base + wc * 32 + (lane & 31);
+      atomicAdd(p.dw + (int64_t)co * p.Cin + ci, acc[o][e]);
+      if (do_cs && (lane & 31) == 0) atomicAdd(p.colsum + co, cs[o][e]);
+    }
+  }
+}
+
 template <int NCO, int NCI>
 int launch_w11(const W11Args& p, int gy, int gz, hipStream_t st) {
   const size_t lds = (size_t)(NCO + NCI) * 256 * 64 > 32768 ? (size_t)(NCO + NCI) * 256 * 64 : 32768;
@@ -365,6 +456,26 @@ int mi_launch_wgrad1x1(const void* x, int x_cs, int Cin, const void* dy, int dy_
   p.x = (const bf16*)x; p.x_cs = x_cs; p.Cin = Cin; p.dy = (const bf16*)dy; p.dy_cs = dy_cs; p.Cout = Cout;
   p.dw = dw; p.colsum = colsum; p.colsum_stride = colsum_stride; p.nvox = (int64_t)N * V; p.vox_per_image = V;
   p.ci0 = 0; p.co0 = 0;
+  {  // wide layers: 128 x 128 workgroup blocks (k_wgrad1x1_wide); MI_W11_WIDE_MIN: smallest channel count that takes it (0: never)
+    static const int wide_min = [] { const char* e = getenv("MI_W11_WIDE_MIN"); return e ? atoi(e) : 256; }();
+    if (wide_min > 0 && Cin >= wide_min && Cout >= wide_min && Cin % 128 == 0 && Cout % 128 == 0 && (!colsum || colsum_stride == 0)) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_wgrad1x1_wide, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+      }
+      const int gy = Cin / 128, gz = Cout / 128;
+      const int64_t ntiles = (p.nvox + 255) / 256;
+      static const int wide_wgs = [] { const char* e = getenv("MI_W11_WIDE_WGS"); return e && atoi(e) > 0 ? atoi(e) : 256; }();
+      int gx = wide_wgs / (gy * gz);
+      if (gx < 1) gx = 1;
+      if (gx > ntiles) gx = (int)ntiles;
+      hipLaunchKernelGGL(k_wgrad1x1_wide, dim3(gx, gy, gz), dim3(512), 8 * 256 * 64, st, p);
+      MI_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   const int nci = (Cin + 31) / 32, nco = (Cout + 31) / 32;
   const int NCO = nco % 2 == 0 ? 2 : 1;
   const int NCI = (NCO == 1 && nci % 3 == 0) ? 3 : (nci % 2 == 0 ? 2 : 1);  // (2 x 3 pairs of accumulators would spill)
