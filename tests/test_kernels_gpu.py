@@ -506,3 +506,19 @@ def test_linear_weight_gradient_matches_fp32(rows, fin, fout):
     want_b = db0.double() + dy.double().sum(0)
     check(dw.cpu().double(), want_w, 2e-3, "linear dW")
     check(db.cpu().double(), want_b, 2e-3, "linear db")
+
+
+@pytest.mark.parametrize("rows,fin,fout", [(4100, 256, 512), (700, 64, 96)])
+def test_linear_weight_gradient_on_channel_slices(rows, fin, fout):
+    """The same entry point on operands that are channel slices of wider buffers (row pitch > features: the 1x1 shortcut conv of a
+    ResnetBlock reads a slice of the skip-concat buffer), wide and narrow kernels."""
+    from medical_image_generation_amd._lib import call, ptr
+    ldx, ldy = fin + 64, fout + 128
+    xw, dyw = rnd(rows, ldx, seed=5), rnd(rows, ldy, seed=6)
+    xb, dyb = xw.to(dev).bfloat16().contiguous(), dyw.to(dev).bfloat16().contiguous()
+    dw, db = torch.zeros(fout, fin, device=dev), torch.zeros(fout, device=dev)
+    call("mi_linear_wgrad_bf16", xb.data_ptr() + 2 * 32, ldx, fin, dyb.data_ptr() + 2 * 64, ldy, fout, rows, ptr(dw), ptr(db))
+    torch.cuda.synchronize()
+    x, dy = xw[:, 32:32 + fin].double(), dyw[:, 64:64 + fout].double()
+    check(dw.cpu().double(), dy.t() @ x, 2e-3, "linear dW (slices)")
+    check(db.cpu().double(), dy.sum(0), 2e-3, "linear db (slices)")
